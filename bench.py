@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s through transform -> vumeter on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c4|c3|c5]
+
+A step is one pass of the hot path over one batch that is already resident in HBM:
+one fused gain(+channel map) -> VU launch over every stream of the rank's shard, the
+asynchronous snapshot of all VU windows to the host, and the host-side dB finish
+(double, as the reference) of the previous step's windows, overlapped with the GPU.
+
+Workloads (per GPU; stream s of the node lives on rank s % N -- round-robin shards,
+no data-path collective, "weak" scaling):
+  c2  4096 stereo streams x 65536 frames, channel swap + gains {750,1250}/1000, PCM
+      materialised (2 B read + 2 B written per sample)             [default, configs[1]]
+  c4  8192 mono streams x 65536 frames, gain 900/1000, PCM materialised  [configs[3]]
+  c5  c4 + node-global VU: one RCCL all-reduce pair per step             [configs[4]]
+  c3  8192 mono streams, int16 -> float + 3-band EQ, float out           [configs[2]]
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, timed with HIP
+events on the stream it is launched on; `cpu_baseline` is the CPU oracle (the scalar
+restatement of the reference loops) timed on this host, N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (streams/GPU, channels, frames, bytes per sample, description)
+    "c2": (4096, 2, 65536, 4, "4096 stereo int16 48 kHz streams x 65536 frames per GPU, "
+                              "channel swap + gains {750,1250}/1000 -> VU, PCM materialised"),
+    "c4": (8192, 1, 65536, 4, "8192 mono int16 streams x 65536 frames per GPU (65536 streams "
+                              "round-robin over 8 GPUs), gain 900/1000 -> VU, PCM materialised"),
+    "c5": (8192, 1, 65536, 4, "c4 + node-global VU via RCCL all-reduce each step"),
+    "c3": (8192, 1, 65536, 6, "8192 mono streams x 65536 frames per GPU, int16 -> float + "
+                              "3-band biquad EQ, planar float out"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=0, help="override frames per launch")
+    ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip ceilings / VU-only line")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus %d needs one process per GPU: launch with "
+                     "python -m torch.distributed.run --nproc-per-node %d ..." % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as ge
+    cm = ge.load_package()
+
+    if cm.device_count() < 1:
+        sys.exit("bench.py: no HIP device; this path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    S, Cn, T, bps, desc = WORKLOADS[args.workload]
+    if args.frames:
+        T = args.frames
+    if args.streams:
+        S = args.streams
+    eq = args.workload == "c3"
+    node_vu = args.workload == "c5"
+
+    if eq:
+        flags = cm.EQ | cm.OUT_F32
+    else:
+        flags = cm.OUT_PCM | cm.VU
+    b = cm.Batch(S, Cn, T, flags=flags, device=local_rank)
+    if args.workload == "c2":
+        assert b.set_gain(-1, 2, 1000, [750, 1250]) == 0
+        assert b.set_chmap(-1, [1, 0]) == 0
+    else:
+        assert b.set_gain(-1, 1, 1000, [900]) == 0
+    if eq:
+        assert b.set_eq(-1, cm.eq3(48000.0)) == 0
+    # global stream id of local stream s is rank + s*world (round-robin sharding)
+    b.generate(cm.GEN_NOISE, 12345, T, first_global=rank, global_step=world)
+    b.sync()
+
+    has_vu = bool(flags & cm.VU)
+    results = (cm.VuResult * S)()
+    rcs = (C.c_int * S)()
+    node_words = torch.zeros(cm.NODE_WORDS, dtype=torch.int64, device="cuda") if node_vu else None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_steps(n):
+        pending = False
+        for _ in range(n):
+            b.run(T)
+            if node_vu and world > 1:
+                b.node_partial(node_words.data_ptr(), first_global=rank, global_step=world)
+                b.sync()      # the record is produced on the batch's stream, RCCL uses torch's
+                dist.all_reduce(node_words[:cm.NODE_WORDS // 2], op=dist.ReduceOp.SUM)
+                dist.all_reduce(node_words[cm.NODE_WORDS // 2:], op=dist.ReduceOp.MAX)
+            if has_vu:
+                if pending:
+                    b.vu_collect(results, rcs)       # dB finish of the previous window (host)
+                b.vu_snapshot()                      # async D2H of all windows + reset
+                pending = True
+        if pending:
+            b.vu_collect(results, rcs)
+        b.sync()
+
+    run_steps(args.warmup)
+    b.timing(True)
+    b.timing_read()
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    kern_ms, launches = b.timing_read()
+    b.timing(False)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    samples_per_step_rank = S * Cn * T
+    total_samples = samples_per_step_rank * world * args.steps
+    value = total_samples / dt / 1e6
+
+    kern_avg_ms = kern_ms / max(launches, 1)
+    achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+            if pmc.get("workload") == args.workload and pmc.get("frames") == T and \
+                    pmc.get("streams") == S:
+                traffic = pmc.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "kernel": "k_eq" if eq else "k_run_fast", "kernel_avg_ms": round(kern_avg_ms, 4),
+        "launches": launches, "algorithmic_bytes_per_sample": bps,
+        "algorithmic_bytes_per_launch": samples_per_step_rank * bps,
+    }
+
+    out = {
+        "metric": "Msamples/s transform->vumeter", "value": round(value, 1), "unit": "Msamples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int16 (int32 product, int64 accumulate)"
+        if not eq else "f32",
+        "data": "synthetic (per-stream LCG noise generated on device, seed 12345 + stream id)",
+        "config": {"workload": "%s: %s" % (args.workload, desc), "streams_per_gpu": S,
+                   "channels": Cn, "frames_per_launch": T, "sharding": "stream s -> rank s %% %d" % world,
+                   "collective": "RCCL all-reduce (int64 SUM + MAX) per step" if node_vu else "none"},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and not args.no_extras and not eq:
+        extras = {}
+        try:
+            extras["hbm_read_ceiling_GBs"] = round(b.ceiling(0, 10), 1)
+            extras["hbm_copy_ceiling_GBs"] = round(b.ceiling(1, 10), 1)
+        except Exception as e:           # measurement extras must not break the line
+            extras["ceiling_error"] = str(e)
+        out["measured_ceilings"] = extras
+    b.close()
+
+    if rank == 0 and not args.no_extras and not eq:
+        # second line of SURVEY 8(d): VU only, 2 B/sample read -- never mixed with the above
+        v = cm.Batch(S, Cn, T, flags=cm.VU, device=local_rank)
+        if args.workload == "c2":
+            v.set_gain(-1, 2, 1000, [750, 1250])
+            v.set_chmap(-1, [1, 0])
+        else:
+            v.set_gain(-1, 1, 1000, [900])
+        v.generate(cm.GEN_NOISE, 12345, T, first_global=rank, global_step=world)
+        for _ in range(3):
+            v.run(T)
+        v.sync()
+        v.timing(True)
+        v.timing_read()
+        for _ in range(10):
+            v.run(T)
+        ms, n = v.timing_read()
+        v.close()
+        gbs = samples_per_step_rank * 2 / (ms / n * 1e-3) / 1e9
+        out["vu_only"] = {"kernel_avg_ms": round(ms / n, 4), "achieved_GBs": round(gbs, 1),
+                          "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+                          "Msamples_per_s_kernel": round(samples_per_step_rank / (ms / n * 1e-3) / 1e6, 1),
+                          "algorithmic_bytes_per_sample": 2}
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args.workload, Cn)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(workload, channels):
+    """The CPU oracle (kind "port": scalar restatement of src/transform.c:101-124 and
+    src/vumeter.c:161-218) on this host, on a bounded sample of the same workload."""
+    from oracle import oracle_ffi
+    lib = oracle_ffi.load()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    frames = 65536
+    per_thread = 48                      # streams per thread: ~10-25 s of CPU work in total
+    streams = cores * per_thread
+    if channels == 2:
+        gain = (C.c_uint16 * 2)(750, 1250)
+        cmap = (C.c_uint8 * 2)(1, 0)
+        cmap_p = C.cast(cmap, C.c_void_p)
+    else:
+        gain = (C.c_uint16 * 1)(900)
+        cmap_p = None
+    chk = C.c_uint64()
+    secs = lib.oracle_bench_block(cores, streams, channels, frames, cmap_p, 1000, gain, 12345,
+                                  C.byref(chk))
+    n_all = streams * frames * channels
+    secs1 = lib.oracle_bench_block(1, per_thread, channels, frames, cmap_p, 1000, gain, 12345,
+                                   C.byref(chk))
+    n_one = per_thread * frames * channels
+    chain_frames = 20_000_000
+    secs_chain = lib.oracle_bench_chain(chain_frames, 1000, 900, C.byref(chk))
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {
+        "value": round(n_all / secs / 1e6, 1), "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "sample": "%d of the workload's streams (%d per thread) x %d frames x %d ch, same "
+                  "generator and parameters, block-at-once" % (streams, per_thread, frames, channels),
+        "one_thread_Msamples_s": round(n_one / secs1 / 1e6, 1),
+        "pull_chain_1024B_one_thread_Msamples_s": round(chain_frames / secs_chain / 1e6, 1),
+        "cpu_model": model,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+/*
+ * coolmic_hip.h -- C ABI of the MI355X batch engine behind the transform -> vumeter path.
+ *
+ * Plain pointers and sizes only.  One cmhip_batch_t owns, on one GPU, a block of
+ * S independent capture streams that share a channel count: their PCM slots in
+ * HBM, their gain / channel-map / EQ parameters and their VU accumulators.  One
+ * cmhip_batch_run() is one pass of the reference's per-sample loops over every
+ * stream of the batch:
+ *
+ *   replaces, per stream and per block:
+ *     __process()            ref: src/transform.c:101-124   (gain, saturate)
+ *     the accumulate loop    ref: src/vumeter.c:161-177     (peak, sum of squares)
+ *     int16 -> float planar  ref: src/enc_vorbis.c:108-115  (optional output)
+ *   and cmhip_batch_vu_result() replaces
+ *     coolmic_vumeter_result ref: src/vumeter.c:189-218     (dB on the host, double)
+ *
+ * The per-stream objects of <coolmic-dsp/transform.h> and <coolmic-dsp/vumeter.h>
+ * sit on top of this engine.  Every function returns a COOLMIC_ERROR_* number
+ * (<coolmic-dsp/coolmic-dsp.h>) unless stated; cmhip_last_error() has the text.
+ *
+ * HBM layout: pcm[stream][frame][channel], int16, each stream's slot contiguous
+ * and 16-byte aligned (cmhip_batch_stride() samples apart).  Planar float output:
+ * f32[stream][channel][frame], planes cmhip_batch_max_frames() apart.
+ */
+#ifndef COOLMIC_HIP_H
+#define COOLMIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <coolmic-dsp/vumeter.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cmhip_batch cmhip_batch_t;
+
+/* what a run produces */
+#define CMHIP_OUT_PCM      0x0001u   /* materialise the transformed int16 PCM */
+#define CMHIP_OUT_F32      0x0002u   /* planar float copy of the transformed PCM */
+#define CMHIP_VU           0x0004u   /* accumulate the VU meters */
+#define CMHIP_INPLACE      0x0008u   /* PCM output overwrites the input slots (as the reference does) */
+#define CMHIP_EQ           0x0010u   /* biquad EQ after the gain (mono batches; float and/or int16 out) */
+
+/* synthetic inputs generated on the device */
+#define CMHIP_GEN_NULL     0         /* zeros, as snddev "null" */
+#define CMHIP_GEN_SINE     1         /* 48-sample sine period, stream s starts at phase 7*s */
+#define CMHIP_GEN_NOISE    2         /* per-stream LCG, seed + global stream id */
+
+#define CMHIP_MAX_EQ_SECTIONS 4
+
+typedef struct cmhip_batch_desc {
+    int          device;          /* HIP device ordinal */
+    unsigned int streams;         /* S >= 1 */
+    unsigned int channels;        /* 1..16, shared by the batch */
+    unsigned int rate;            /* Hz, reported in results */
+    size_t       max_frames;      /* slot capacity per stream, frames */
+    unsigned int flags;           /* CMHIP_* outputs */
+    void        *hip_stream;      /* hipStream_t to launch on, NULL: own stream */
+} cmhip_batch_desc_t;
+
+/* ---- process level ------------------------------------------------------- */
+int          cmhip_device_count(void);            /* 0 without a usable GPU */
+const char  *cmhip_last_error(void);              /* per-thread text of the last failure */
+const char  *cmhip_version(void);
+
+/* ---- life cycle ---------------------------------------------------------- */
+cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc);   /* NULL on failure */
+void           cmhip_batch_free(cmhip_batch_t *b);
+
+/* ---- parameters (take effect at the next run) ---------------------------- */
+/* same meaning and return values as coolmic_transform_set_master_gain
+ * (ref: src/transform.c:195-222); stream == -1 addresses every stream */
+int cmhip_batch_set_gain(cmhip_batch_t *b, long stream, unsigned int channels, uint16_t scale,
+                         const uint16_t *gain);
+/* out channel c reads input channel map[c]; NULL = identity */
+int cmhip_batch_set_chmap(cmhip_batch_t *b, long stream, const uint8_t *map);
+/* nsec biquads, 5 floats each {b0,b1,b2,a1,a2} (a0-normalised); nsec 0 = bypass.
+ * Filter state is kept per stream across runs; cmhip_batch_eq_reset() zeroes it. */
+int cmhip_batch_set_eq(cmhip_batch_t *b, long stream, unsigned int nsec, const float *coef);
+int cmhip_batch_eq_reset(cmhip_batch_t *b, long stream);
+/* RBJ designs on the host in double, cast to float: kind 0 low shelf, 1 peaking, 2 high
+ * shelf (shelf slope 1).  coef receives 5 floats. */
+void cmhip_design_biquad(int kind, double rate, double freq, double gain_db, double q,
+                         float *coef);
+
+/* ---- geometry and raw device pointers ------------------------------------ */
+size_t  cmhip_batch_stride(const cmhip_batch_t *b);       /* samples between stream slots */
+size_t  cmhip_batch_max_frames(const cmhip_batch_t *b);
+void   *cmhip_batch_dev_in(cmhip_batch_t *b);             /* int16 [S][stride] */
+void   *cmhip_batch_dev_out(cmhip_batch_t *b);            /* int16 [S][stride] (== in when INPLACE) */
+void   *cmhip_batch_dev_f32(cmhip_batch_t *b);            /* float [S][C][max_frames] or NULL */
+void   *cmhip_batch_hip_stream(cmhip_batch_t *b);         /* the hipStream_t launches go to */
+
+/* ---- moving PCM (asynchronous on the batch's stream) ---------------------- */
+int cmhip_batch_upload(cmhip_batch_t *b, unsigned int stream, const int16_t *pcm, size_t frames);
+int cmhip_batch_download(cmhip_batch_t *b, unsigned int stream, int16_t *pcm, size_t frames);
+/* reads an input slot back (generated or uploaded PCM); synchronises */
+int cmhip_batch_download_input(cmhip_batch_t *b, unsigned int stream, int16_t *pcm, size_t frames);
+int cmhip_batch_download_f32(cmhip_batch_t *b, unsigned int stream, unsigned int channel,
+                             float *dst, size_t frames);
+/* fill every stream's input slot on the device; stream s of this batch is global
+ * stream first_global + s*global_step (round-robin shards use first=rank, step=N) */
+int cmhip_batch_generate(cmhip_batch_t *b, int mode, uint32_t seed, size_t frames,
+                         uint64_t first_global, uint64_t global_step, uint64_t frame_offset);
+
+/* ---- the hot path --------------------------------------------------------- */
+/* process `frames` frames of every stream (frames_per_stream, if not NULL, gives each
+ * stream its own count <= frames; host array of S entries).  Asynchronous. */
+int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per_stream);
+int cmhip_batch_sync(cmhip_batch_t *b);
+
+/* ---- VU windows ------------------------------------------------------------ */
+/* result of one stream's current window, then reset of that window -- the contract of
+ * coolmic_vumeter_result (ref: src/vumeter.c:189-218), INVAL while it holds no frame */
+int cmhip_batch_vu_result(cmhip_batch_t *b, unsigned int stream, coolmic_vumeter_result_t *out);
+/* all streams at once: out[S], rc[S] (rc may be NULL); one device round trip */
+int cmhip_batch_vu_results(cmhip_batch_t *b, coolmic_vumeter_result_t *out, int *rc);
+/* two-phase form that overlaps with the next run: snapshot copies the accumulators of
+ * every stream to pinned host memory and opens a new window on the device (async);
+ * collect waits for that copy and finishes the dB values on the host */
+int cmhip_batch_vu_snapshot(cmhip_batch_t *b);
+int cmhip_batch_vu_collect(cmhip_batch_t *b, coolmic_vumeter_result_t *out, int *rc);
+int cmhip_batch_vu_reset(cmhip_batch_t *b, long stream);
+/* raw accumulators of a stream (synchronises): power[16], peak[16], frames */
+int cmhip_batch_vu_raw(cmhip_batch_t *b, unsigned int stream, int64_t *power, int16_t *peak,
+                       uint64_t *frames);
+
+/* ---- node-global VU ---------------------------------- */
+/* Reduces this batch's current windows over its streams into one record of
+ * CMHIP_NODE_WORDS int64 words written to device memory `dst` (asynchronous):
+ *   [0..15]  sum of squares per channel      -> combine across GPUs with SUM
+ *   [16]     frames summed over streams      -> SUM
+ *   [17..32] packed peak key per channel     -> combine with MAX
+ *   [33]     packed global peak key          -> MAX
+ * Keys order by (|peak|, earliest frame, lowest global stream id); decode with
+ * cmhip_node_finish().  The all-reduce itself is two RCCL calls on `dst` made by
+ * the caller (torch.distributed with backend "nccl" in bench.py). */
+#define CMHIP_NODE_WORDS      34
+#define CMHIP_NODE_SUM_WORDS  17
+int cmhip_batch_vu_node_partial(cmhip_batch_t *b, void *dst_device, uint64_t first_global,
+                                uint64_t global_step);
+/* host: turn a combined record into a result (frames = total frames over streams) */
+int cmhip_node_finish(const int64_t *words, unsigned int channels, unsigned int rate,
+                      coolmic_vumeter_result_t *out);
+
+/* ---- measurement ----------------------------------------------------------- */
+/* when enabled every run is bracketed by hipEvents on the batch's stream */
+int cmhip_batch_timing(cmhip_batch_t *b, int enable);
+/* sums since the last call: milliseconds and launches of the dominant kernel; resets */
+int cmhip_batch_timing_read(cmhip_batch_t *b, double *kernel_ms, unsigned int *launches);
+/* plain HBM ceilings measured with the same buffers: mode 0 read-only sum, 1 copy.
+ * Returns GB/s of algorithmic bytes (read: bytes; copy: 2*bytes) or <0 on error. */
+double cmhip_batch_ceiling(cmhip_batch_t *b, int mode, size_t frames, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,516 @@
+"""ctypes view of lib/libcoolmic-dsp-hip.so for tests and bench.py.
+
+Two layers, both thin:
+  * `Batch` mirrors the C ABI of include/coolmic_hip.h (the MI355X batch engine);
+  * `Transform`, `Vumeter`, `Snddev`, `IoHandle` mirror the reference's per-stream
+    operator API of include/coolmic-dsp/*.h (same function names underneath, same
+    argument meaning and error numbers), so tests read like tests of the reference.
+
+There is no fallback of any kind: if the shared object is missing, import fails.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcoolmic-dsp-hip.so")
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C {_HERE}` "
+        "(or __graft_entry__.build()); there is no CPU fallback")
+
+lib = C.CDLL(LIB_PATH)
+
+MAX_CH = 16
+ssize_t = C.c_ssize_t
+
+# error numbers (include/coolmic-dsp/coolmic-dsp.h)
+ERROR_NONE, ERROR_GENERIC, ERROR_NOSYS, ERROR_FAULT = 0, -1, -8, -9
+ERROR_INVAL, ERROR_NOMEM, ERROR_BUSY = -10, -11, -12
+
+OUT_PCM, OUT_F32, VU, INPLACE, EQ = 0x1, 0x2, 0x4, 0x8, 0x10
+GEN_NULL, GEN_SINE, GEN_NOISE = 0, 1, 2
+NODE_WORDS = 34
+
+READ_FN = C.CFUNCTYPE(ssize_t, C.c_void_p, C.c_void_p, C.c_size_t)
+EOF_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+FREE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+LOG_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_char_p)
+
+
+class VuResult(C.Structure):
+    """coolmic_vumeter_result_t (include/coolmic-dsp/vumeter.h)"""
+    _fields_ = [("rate", C.c_uint32), ("channels", C.c_uint), ("frames", C.c_size_t),
+                ("global_peak", C.c_int16), ("global_power", C.c_double),
+                ("channel_peak", C.c_int16 * MAX_CH), ("channel_power", C.c_double * MAX_CH)]
+
+    def as_dict(self):
+        ch = self.channels
+        return {"rate": self.rate, "channels": ch, "frames": self.frames,
+                "global_peak": self.global_peak, "global_power": self.global_power,
+                "channel_peak": [self.channel_peak[i] for i in range(ch)],
+                "channel_power": [self.channel_power[i] for i in range(ch)]}
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [("device", C.c_int), ("streams", C.c_uint), ("channels", C.c_uint),
+                ("rate", C.c_uint), ("max_frames", C.c_size_t), ("flags", C.c_uint),
+                ("hip_stream", C.c_void_p)]
+
+
+def _sig(name, res, args):
+    fn = getattr(lib, name)
+    fn.restype = res
+    fn.argtypes = args
+    return fn
+
+
+_P = C.POINTER
+_vp = C.c_void_p
+# every symbol include/*.h declares; tests/test_abi.py checks this table against the headers
+SIGNATURES = {
+    # include/coolmic_hip.h
+    "cmhip_device_count": (C.c_int, []),
+    "cmhip_last_error": (C.c_char_p, []),
+    "cmhip_version": (C.c_char_p, []),
+    "cmhip_batch_new": (_vp, [_P(BatchDesc)]),
+    "cmhip_batch_free": (None, [_vp]),
+    "cmhip_batch_set_gain": (C.c_int, [_vp, C.c_long, C.c_uint, C.c_uint16, _P(C.c_uint16)]),
+    "cmhip_batch_set_chmap": (C.c_int, [_vp, C.c_long, _vp]),
+    "cmhip_batch_set_eq": (C.c_int, [_vp, C.c_long, C.c_uint, _vp]),
+    "cmhip_batch_eq_reset": (C.c_int, [_vp, C.c_long]),
+    "cmhip_design_biquad": (None, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _vp]),
+    "cmhip_batch_stride": (C.c_size_t, [_vp]),
+    "cmhip_batch_max_frames": (C.c_size_t, [_vp]),
+    "cmhip_batch_dev_in": (_vp, [_vp]),
+    "cmhip_batch_dev_out": (_vp, [_vp]),
+    "cmhip_batch_dev_f32": (_vp, [_vp]),
+    "cmhip_batch_hip_stream": (_vp, [_vp]),
+    "cmhip_batch_upload": (C.c_int, [_vp, C.c_uint, _vp, C.c_size_t]),
+    "cmhip_batch_download": (C.c_int, [_vp, C.c_uint, _vp, C.c_size_t]),
+    "cmhip_batch_download_input": (C.c_int, [_vp, C.c_uint, _vp, C.c_size_t]),
+    "cmhip_batch_download_f32": (C.c_int, [_vp, C.c_uint, C.c_uint, _vp, C.c_size_t]),
+    "cmhip_batch_generate": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_size_t, C.c_uint64,
+                                       C.c_uint64, C.c_uint64]),
+    "cmhip_batch_run": (C.c_int, [_vp, C.c_size_t, _vp]),
+    "cmhip_batch_sync": (C.c_int, [_vp]),
+    "cmhip_batch_vu_result": (C.c_int, [_vp, C.c_uint, _P(VuResult)]),
+    "cmhip_batch_vu_results": (C.c_int, [_vp, _vp, _vp]),
+    "cmhip_batch_vu_snapshot": (C.c_int, [_vp]),
+    "cmhip_batch_vu_collect": (C.c_int, [_vp, _vp, _vp]),
+    "cmhip_batch_vu_reset": (C.c_int, [_vp, C.c_long]),
+    "cmhip_batch_vu_raw": (C.c_int, [_vp, C.c_uint, _vp, _vp, _P(C.c_uint64)]),
+    "cmhip_batch_vu_node_partial": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64]),
+    "cmhip_node_finish": (C.c_int, [_vp, C.c_uint, C.c_uint, _P(VuResult)]),
+    "cmhip_batch_timing": (C.c_int, [_vp, C.c_int]),
+    "cmhip_batch_timing_read": (C.c_int, [_vp, _P(C.c_double), _P(C.c_uint)]),
+    "cmhip_batch_ceiling": (C.c_double, [_vp, C.c_int, C.c_size_t, C.c_int]),
+    # include/coolmic-dsp/ro-compat.h
+    "coolmic_ro_new_raw": (_vp, [_vp, C.c_char_p, _vp]),
+    "coolmic_ro_ref": (C.c_int, [_vp]),
+    "coolmic_ro_unref": (C.c_int, [_vp]),
+    "coolmic_ro_refcount": (C.c_uint, [_vp]),
+    # include/coolmic-dsp/coolmic-dsp.h
+    "coolmic_error2string": (C.c_char_p, [C.c_int]),
+    "coolmic_features": (C.c_char_p, []),
+    "coolmic_feature_check": (C.c_int, [C.c_char_p]),
+    # include/coolmic-dsp/logging.h
+    "coolmic_logging_level2string": (C.c_char_p, [C.c_int]),
+    "coolmic_logging_log_real": (C.c_int, None),
+    "coolmic_logging_set_cb_simple": (C.c_int, [LOG_FN]),
+    # include/coolmic-dsp/iohandle.h
+    "coolmic_iohandle_new": (_vp, [C.c_char_p, _vp, _vp, FREE_FN, READ_FN, EOF_FN]),
+    "coolmic_iohandle_read": (ssize_t, [_vp, _vp, C.c_size_t]),
+    "coolmic_iohandle_eof": (C.c_int, [_vp]),
+    # include/coolmic-dsp/transform.h
+    "coolmic_transform_new": (_vp, [C.c_char_p, _vp, C.c_uint32, C.c_uint]),
+    "coolmic_transform_attach_iohandle": (C.c_int, [_vp, _vp]),
+    "coolmic_transform_get_iohandle": (_vp, [_vp]),
+    "coolmic_transform_set_master_gain": (C.c_int, [_vp, C.c_uint, C.c_uint16, _P(C.c_uint16)]),
+    "coolmic_transform_set_channel_map": (C.c_int, [_vp, _vp]),
+    # include/coolmic-dsp/vumeter.h
+    "coolmic_vumeter_new": (_vp, [C.c_char_p, _vp, C.c_uint32, C.c_uint]),
+    "coolmic_vumeter_reset": (C.c_int, [_vp]),
+    "coolmic_vumeter_attach_iohandle": (C.c_int, [_vp, _vp]),
+    "coolmic_vumeter_read": (ssize_t, [_vp, ssize_t]),
+    "coolmic_vumeter_result": (C.c_int, [_vp, _P(VuResult)]),
+    # include/coolmic-dsp/snddev.h
+    "coolmic_snddev_new": (_vp, [C.c_char_p, _vp, C.c_char_p, _vp, C.c_uint32, C.c_uint, C.c_int,
+                                 ssize_t]),
+    "coolmic_snddev_get_iohandle": (_vp, [_vp]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    if _args is not None:
+        _fn.argtypes = _args
+
+# not in a public header: host-logic test hooks
+lib.cmhip_test_magic.restype = None
+lib.cmhip_test_magic.argtypes = [C.c_uint16, _P(C.c_uint32), _P(C.c_uint32)]
+lib.coolmic_sine_period.restype = C.c_int
+lib.coolmic_sine_period.argtypes = [C.c_uint32, _vp, _P(C.c_size_t)]
+
+
+class CoolmicError(RuntimeError):
+    def __init__(self, what, code):
+        text = lib.coolmic_error2string(code).decode()
+        detail = lib.cmhip_last_error().decode()
+        super().__init__(f"{what}: {code} ({text}) {detail}")
+        self.code = code
+
+
+def _check(what, rc):
+    if rc != ERROR_NONE:
+        raise CoolmicError(what, rc)
+
+
+def device_count():
+    return lib.cmhip_device_count()
+
+
+def last_error():
+    return lib.cmhip_last_error().decode()
+
+
+def magic(scale):
+    m, s = C.c_uint32(), C.c_uint32()
+    lib.cmhip_test_magic(scale, C.byref(m), C.byref(s))
+    return m.value, s.value
+
+
+def sine_period(rate):
+    buf = np.zeros(96, dtype=np.int16)
+    n = C.c_size_t()
+    rc = lib.coolmic_sine_period(rate, buf.ctypes.data, C.byref(n))
+    return rc, buf[: n.value].copy()
+
+
+def design_biquad(kind, rate, freq, gain_db, q=0.0):
+    out = np.zeros(5, dtype=np.float32)
+    lib.cmhip_design_biquad(kind, rate, freq, gain_db, q, out.ctypes.data)
+    return out
+
+
+def eq3(rate=48000.0):
+    """the 3-band EQ of BASELINE config 3"""
+    return np.concatenate([design_biquad(0, rate, 200.0, 3.0),
+                           design_biquad(1, rate, 1000.0, -2.0, 1.0),
+                           design_biquad(2, rate, 6000.0, 2.0)]).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# the batch engine
+
+
+class Batch:
+    def __init__(self, streams, channels, max_frames, flags=OUT_PCM | VU, rate=48000, device=0,
+                 hip_stream=None):
+        d = BatchDesc(device, streams, channels, rate, max_frames, flags, hip_stream)
+        self.h = lib.cmhip_batch_new(C.byref(d))
+        if not self.h:
+            raise CoolmicError("cmhip_batch_new", ERROR_GENERIC)
+        self.streams, self.channels, self.max_frames, self.flags = streams, channels, max_frames, flags
+        self.rate = rate
+
+    def close(self):
+        if self.h:
+            lib.cmhip_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # parameters
+    def set_gain(self, stream, channels, scale, gains):
+        arr = (C.c_uint16 * len(gains))(*gains) if gains is not None and len(gains) else None
+        return lib.cmhip_batch_set_gain(self.h, stream, channels, scale, arr)
+
+    def set_chmap(self, stream, cmap):
+        if cmap is None:
+            return lib.cmhip_batch_set_chmap(self.h, stream, None)
+        m = np.asarray(cmap, dtype=np.uint8)
+        return lib.cmhip_batch_set_chmap(self.h, stream, m.ctypes.data)
+
+    def set_eq(self, stream, coef):
+        c = np.ascontiguousarray(coef, dtype=np.float32).reshape(-1)
+        return lib.cmhip_batch_set_eq(self.h, stream, c.size // 5, c.ctypes.data if c.size else None)
+
+    def eq_reset(self, stream=-1):
+        _check("eq_reset", lib.cmhip_batch_eq_reset(self.h, stream))
+
+    # data
+    def upload(self, stream, pcm):
+        a = np.ascontiguousarray(pcm, dtype=np.int16)
+        _check("upload", lib.cmhip_batch_upload(self.h, stream, a.ctypes.data, a.size // self.channels))
+
+    def download(self, stream, frames):
+        out = np.empty(frames * self.channels, dtype=np.int16)
+        _check("download", lib.cmhip_batch_download(self.h, stream, out.ctypes.data, frames))
+        return out
+
+    def download_f32(self, stream, channel, frames):
+        out = np.empty(frames, dtype=np.float32)
+        _check("download_f32", lib.cmhip_batch_download_f32(self.h, stream, channel,
+                                                            out.ctypes.data, frames))
+        return out
+
+    def generate(self, mode, seed, frames, first_global=0, global_step=1, frame_offset=0):
+        _check("generate", lib.cmhip_batch_generate(self.h, mode, seed & 0xFFFFFFFF, frames,
+                                                    first_global, global_step, frame_offset))
+
+    def download_input(self, stream, frames):
+        out = np.empty(frames * self.channels, dtype=np.int16)
+        _check("download_input", lib.cmhip_batch_download_input(self.h, stream, out.ctypes.data,
+                                                                frames))
+        return out
+
+    # hot path
+    def run(self, frames, frames_per_stream=None):
+        if frames_per_stream is None:
+            _check("run", lib.cmhip_batch_run(self.h, frames, None))
+        else:
+            a = np.ascontiguousarray(frames_per_stream, dtype=np.uint32)
+            assert a.size == self.streams
+            _check("run", lib.cmhip_batch_run(self.h, frames, a.ctypes.data))
+
+    def sync(self):
+        _check("sync", lib.cmhip_batch_sync(self.h))
+
+    # VU
+    def vu_result(self, stream):
+        r = VuResult()
+        rc = lib.cmhip_batch_vu_result(self.h, stream, C.byref(r))
+        return rc, r
+
+    def vu_results(self):
+        out = (VuResult * self.streams)()
+        rc = (C.c_int * self.streams)()
+        _check("vu_results", lib.cmhip_batch_vu_results(self.h, out, rc))
+        return out, list(rc)
+
+    def vu_snapshot(self):
+        _check("vu_snapshot", lib.cmhip_batch_vu_snapshot(self.h))
+
+    def vu_collect(self, out=None, rc=None):
+        out = out if out is not None else (VuResult * self.streams)()
+        rc = rc if rc is not None else (C.c_int * self.streams)()
+        _check("vu_collect", lib.cmhip_batch_vu_collect(self.h, out, rc))
+        return out, rc
+
+    def vu_reset(self, stream=-1):
+        _check("vu_reset", lib.cmhip_batch_vu_reset(self.h, stream))
+
+    def vu_raw(self, stream):
+        power = np.zeros(MAX_CH, dtype=np.int64)
+        peak = np.zeros(MAX_CH, dtype=np.int16)
+        frames = C.c_uint64()
+        _check("vu_raw", lib.cmhip_batch_vu_raw(self.h, stream, power.ctypes.data, peak.ctypes.data,
+                                                C.byref(frames)))
+        return power, peak, frames.value
+
+    def node_partial(self, dst_device_ptr, first_global=0, global_step=1):
+        _check("node_partial", lib.cmhip_batch_vu_node_partial(self.h, dst_device_ptr, first_global,
+                                                               global_step))
+
+    # measurement
+    def timing(self, enable):
+        _check("timing", lib.cmhip_batch_timing(self.h, 1 if enable else 0))
+
+    def timing_read(self):
+        ms, n = C.c_double(), C.c_uint()
+        _check("timing_read", lib.cmhip_batch_timing_read(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def ceiling(self, mode, iters=10):
+        return lib.cmhip_batch_ceiling(self.h, mode, self.max_frames, iters)
+
+    @property
+    def stride(self):
+        return lib.cmhip_batch_stride(self.h)
+
+    @property
+    def dev_in(self):
+        return lib.cmhip_batch_dev_in(self.h)
+
+    @property
+    def dev_out(self):
+        return lib.cmhip_batch_dev_out(self.h)
+
+
+def node_finish(words, channels, rate=48000):
+    w = np.ascontiguousarray(words, dtype=np.int64)
+    assert w.size == NODE_WORDS
+    r = VuResult()
+    rc = lib.cmhip_node_finish(w.ctypes.data, channels, rate, C.byref(r))
+    return rc, r
+
+
+# ---------------------------------------------------------------------------
+# the reference's per-stream operator API
+
+
+_alive = {}
+
+
+class IoHandle:
+    """Owns one reference to a coolmic_iohandle_t."""
+
+    def __init__(self, ptr, keep=()):
+        if not ptr:
+            raise CoolmicError("iohandle", ERROR_GENERIC)
+        self.ptr = ptr
+        self._keep = keep
+
+    @classmethod
+    def from_callbacks(cls, read, eof=None, free=None):
+        """read(nbytes) -> bytes | int(<=0); eof() -> int.  The ctypes thunks stay alive
+        until the C side runs the handle's free callback (i.e. until the last unref)."""
+        token = object()
+
+        def _read(_ud, buf, n):
+            got = read(n)
+            if isinstance(got, int):
+                return got
+            got = bytes(got)[:n]
+            C.memmove(buf, got, len(got))
+            return len(got)
+
+        def _free(_ud):
+            if free:
+                free()
+            _alive.pop(id(token), None)
+            return 0
+
+        rcb = READ_FN(_read)
+        ecb = EOF_FN((lambda _ud: eof())) if eof else EOF_FN()
+        fcb = FREE_FN(_free)
+        _alive[id(token)] = (token, rcb, ecb, fcb)
+        ptr = lib.coolmic_iohandle_new(None, None, None, fcb, rcb, ecb)
+        if not ptr:
+            _alive.pop(id(token), None)
+        return cls(ptr)
+
+    @classmethod
+    def from_bytes(cls, data, chunk=0):
+        """serves `data` in pieces of at most `chunk` bytes (0: as asked), then reports EOF"""
+        state = {"pos": 0}
+        data = bytes(data)
+
+        def read(n):
+            k = min(n, len(data) - state["pos"])
+            if chunk:
+                k = min(k, chunk)
+            out = data[state["pos"]: state["pos"] + k]
+            state["pos"] += k
+            return out
+
+        return cls.from_callbacks(read, eof=lambda: 1 if state["pos"] >= len(data) else 0)
+
+    def read(self, nbytes):
+        buf = (C.c_ubyte * max(nbytes, 1))()
+        n = lib.coolmic_iohandle_read(self.ptr, buf, nbytes)
+        return n, bytes(buf[: max(n, 0)])
+
+    def eof(self):
+        return lib.coolmic_iohandle_eof(self.ptr)
+
+    def refcount(self):
+        return lib.coolmic_ro_refcount(self.ptr)
+
+    def unref(self):
+        if self.ptr:
+            lib.coolmic_ro_unref(self.ptr)
+            self.ptr = None
+
+
+class Snddev:
+    def __init__(self, driver, rate=48000, channels=1, flags=1):
+        self.ptr = lib.coolmic_snddev_new(None, None, driver.encode() if driver else None, None,
+                                          rate, channels, flags, -1)
+        if not self.ptr:
+            raise CoolmicError("coolmic_snddev_new", ERROR_GENERIC)
+
+    def get_iohandle(self):
+        return IoHandle(lib.coolmic_snddev_get_iohandle(self.ptr))
+
+    def unref(self):
+        if self.ptr:
+            lib.coolmic_ro_unref(self.ptr)
+            self.ptr = None
+
+
+class Transform:
+    def __init__(self, rate=48000, channels=1):
+        self.ptr = lib.coolmic_transform_new(None, None, rate, channels)
+        if not self.ptr:
+            raise CoolmicError("coolmic_transform_new", ERROR_GENERIC)
+        self.channels = channels
+
+    def attach(self, handle):
+        return lib.coolmic_transform_attach_iohandle(self.ptr, handle.ptr if handle else None)
+
+    def get_iohandle(self):
+        return IoHandle(lib.coolmic_transform_get_iohandle(self.ptr))
+
+    def set_master_gain(self, channels, scale, gains):
+        arr = (C.c_uint16 * len(gains))(*gains) if gains is not None and len(gains) else None
+        return lib.coolmic_transform_set_master_gain(self.ptr, channels, scale, arr)
+
+    def set_channel_map(self, cmap):
+        if cmap is None:
+            return lib.coolmic_transform_set_channel_map(self.ptr, None)
+        m = np.asarray(cmap, dtype=np.uint8)
+        return lib.coolmic_transform_set_channel_map(self.ptr, m.ctypes.data)
+
+    def refcount(self):
+        return lib.coolmic_ro_refcount(self.ptr)
+
+    def unref(self):
+        if self.ptr:
+            lib.coolmic_ro_unref(self.ptr)
+            self.ptr = None
+
+
+class Vumeter:
+    def __init__(self, rate=48000, channels=1):
+        self.ptr = lib.coolmic_vumeter_new(None, None, rate, channels)
+        if not self.ptr:
+            raise CoolmicError("coolmic_vumeter_new", ERROR_GENERIC)
+        self.channels = channels
+
+    def attach(self, handle):
+        return lib.coolmic_vumeter_attach_iohandle(self.ptr, handle.ptr if handle else None)
+
+    def read(self, maxlen=-1):
+        return lib.coolmic_vumeter_read(self.ptr, maxlen)
+
+    def result(self):
+        r = VuResult()
+        rc = lib.coolmic_vumeter_result(self.ptr, C.byref(r))
+        return rc, r
+
+    def reset(self):
+        return lib.coolmic_vumeter_reset(self.ptr)
+
+    def unref(self):
+        if self.ptr:
+            lib.coolmic_ro_unref(self.ptr)
+            self.ptr = None
+
+
+_log_keep = []
+
+
+def set_log_callback(fn):
+    """fn(level:int, msg:str) or None"""
+    if fn is None:
+        lib.coolmic_logging_set_cb_simple(LOG_FN())
+        return
+    cb = LOG_FN(lambda lvl, msg: fn(lvl, msg.decode(errors="replace")) or 0)
+    _log_keep.append(cb)
+    lib.coolmic_logging_set_cb_simple(cb)

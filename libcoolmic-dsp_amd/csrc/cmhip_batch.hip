@@ -1,0 +1,972 @@
+// cmhip_batch.hip -- the batch engine behind include/coolmic_hip.h.
+//
+// Host side of the MI355X path: owns the HBM slots of S streams, the per-stream
+// parameter table and the VU windows, launches the kernels of cmhip_kernels.hip on
+// one HIP stream and finishes VU windows on the host in double, exactly as the
+// reference does (ref: src/vumeter.c:189-218).  There is no CPU fallback: without a
+// device cmhip_batch_new() fails.
+#include "cmhip_internal.h"
+
+#include <coolmic-dsp/coolmic-dsp.h>
+#include <coolmic_hip.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+extern "C" int coolmic_sine_period(uint_least32_t rate, int16_t *table, size_t *samples);
+
+using namespace cmhip;
+
+// ---------------------------------------------------------------------------
+// errors
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(COOLMIC_ERROR_GENERIC, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+extern "C" const char *cmhip_last_error(void) { return g_err; }
+extern "C" const char *cmhip_version(void) { return "coolmic-dsp-hip 0.1 (gfx950)"; }
+
+extern "C" int cmhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// the batch object
+
+constexpr unsigned STAGE_SLOTS = 4;
+constexpr size_t STAGE_BYTES = 64 * 1024;
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+struct cmhip_batch {
+    cmhip_batch_desc_t d;
+    hipStream_t stream;
+    bool own_stream;
+    size_t stride;                 // samples between slots
+    size_t plane;                  // floats between f32 planes
+
+    int16_t *d_in, *d_out;
+    float *d_f32;
+    StreamParam *d_param;
+    VuState *d_vu;
+    uint32_t *d_nframes;
+    EqParam *d_eq;
+    EqState *d_eqstate;
+    unsigned long long *d_sink;
+
+    std::vector<StreamParam> h_param;
+    std::vector<uint16_t> h_scale;         // the reference's master_gain_scale per stream
+    std::vector<uint16_t> h_gain;          // [S][16]
+    bool param_dirty;
+    std::vector<EqParam> h_eq;
+    unsigned int nsec;
+    bool eq_dirty;
+
+    VuState *h_snap;                       // pinned, S entries
+    unsigned char *h_stage;                // pinned upload ring, STAGE_SLOTS x STAGE_BYTES
+    hipEvent_t stage_ev[4];
+    bool stage_busy[4];
+    unsigned int stage_next;
+    hipEvent_t snap_event;
+    bool snap_pending;
+
+    bool timing;
+    std::vector<EventPair> ev_used, ev_free;
+    unsigned int iters_override;
+};
+
+static inline int use(cmhip_batch_t *b)
+{
+    HIP_TRY(hipSetDevice(b->d.device));
+    return COOLMIC_ERROR_NONE;
+}
+
+// magic for floor(n/scale), n < 2^31, via n2 = 2n: q = mulhi(n2, magic) >> shift.
+// With l = ceil(log2 scale) and magic = ceil(2^(31+l)/scale) the error term
+// magic*scale - 2^(31+l) is below scale <= 2^l, which is the Granlund-Montgomery
+// condition for exactness over all n < 2^31.  magic < 2^32 because scale > 2^(l-1).
+static void host_magic(uint16_t scale, uint32_t *magic, uint32_t *shift)
+{
+    uint32_t l = 0;
+    while ((1u << l) < (uint32_t)scale)
+        l++;
+    const unsigned __int128 num = (unsigned __int128)1 << (31 + l);
+    const unsigned __int128 m = (num + scale - 1) / scale;
+    *magic = (uint32_t)m;
+    *shift = l;
+}
+
+static void rebuild_param(cmhip_batch_t *b, unsigned int s)
+{
+    StreamParam &p = b->h_param[s];
+    const uint16_t scale = b->h_scale[s];
+    if (scale == 0) {                       // disabled: identity through the same arithmetic
+        host_magic(1, &p.magic, &p.shift);
+        for (unsigned c = 0; c < MAX_CH; c++)
+            p.gain2[c] = 2u;
+    } else {
+        host_magic(scale, &p.magic, &p.shift);
+        for (unsigned c = 0; c < MAX_CH; c++)
+            p.gain2[c] = 2u * (uint32_t)b->h_gain[(size_t)s * MAX_CH + c];
+    }
+    bool ident = true;
+    for (unsigned c = 0; c < b->d.channels; c++)
+        ident = ident && p.chmap[c] == c;
+    p.map_identity = ident ? 1u : 0u;
+    // stereo map as byte selector: output half h takes input half chmap[h]
+    const uint32_t lo = p.chmap[0] & 1u, hi = p.chmap[1] & 1u;
+    p.perm2 = (2u * lo) | ((2u * lo + 1u) << 8) | ((2u * hi) << 16) | ((2u * hi + 1u) << 24);
+    b->param_dirty = true;
+}
+
+extern "C" void cmhip_batch_free(cmhip_batch_t *b)
+{
+    if (!b)
+        return;
+    (void)hipSetDevice(b->d.device);
+    if (b->stream)
+        (void)hipStreamSynchronize(b->stream);
+    for (auto &e : b->ev_used) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    for (auto &e : b->ev_free) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    if (b->snap_event)
+        (void)hipEventDestroy(b->snap_event);
+    if (b->d_out && b->d_out != b->d_in)
+        (void)hipFree(b->d_out);
+    (void)hipFree(b->d_in);
+    (void)hipFree(b->d_f32);
+    (void)hipFree(b->d_param);
+    (void)hipFree(b->d_vu);
+    (void)hipFree(b->d_nframes);
+    (void)hipFree(b->d_eq);
+    (void)hipFree(b->d_eqstate);
+    (void)hipFree(b->d_sink);
+    if (b->h_snap)
+        (void)hipHostFree(b->h_snap);
+    if (b->h_stage)
+        (void)hipHostFree(b->h_stage);
+    for (unsigned i = 0; i < STAGE_SLOTS; i++)
+        if (b->stage_ev[i])
+            (void)hipEventDestroy(b->stage_ev[i]);
+    if (b->own_stream && b->stream)
+        (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+static int batch_init(cmhip_batch_t *b)
+{
+    const cmhip_batch_desc_t &d = b->d;
+    const size_t S = d.streams;
+    HIP_TRY(hipSetDevice(d.device));
+    if (d.hip_stream) {
+        b->stream = (hipStream_t)d.hip_stream;
+        b->own_stream = false;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        b->own_stream = true;
+    }
+    b->stride = (d.max_frames * d.channels + 7) / 8 * 8;
+    b->plane = (d.max_frames + 63) / 64 * 64;
+
+    const size_t pcm_bytes = S * b->stride * sizeof(int16_t);
+    HIP_TRY(hipMalloc((void **)&b->d_in, pcm_bytes));
+    HIP_TRY(hipMemsetAsync(b->d_in, 0, pcm_bytes, b->stream));
+    if ((d.flags & CMHIP_OUT_PCM) && !(d.flags & CMHIP_INPLACE)) {
+        HIP_TRY(hipMalloc((void **)&b->d_out, pcm_bytes));
+        HIP_TRY(hipMemsetAsync(b->d_out, 0, pcm_bytes, b->stream));
+    } else if (d.flags & CMHIP_OUT_PCM) {
+        b->d_out = b->d_in;
+    }
+    if (d.flags & CMHIP_OUT_F32) {
+        const size_t fbytes = S * d.channels * b->plane * sizeof(float);
+        HIP_TRY(hipMalloc((void **)&b->d_f32, fbytes));
+        HIP_TRY(hipMemsetAsync(b->d_f32, 0, fbytes, b->stream));
+    }
+    HIP_TRY(hipMalloc((void **)&b->d_param, S * sizeof(StreamParam)));
+    HIP_TRY(hipMalloc((void **)&b->d_vu, S * sizeof(VuState)));
+    HIP_TRY(hipMemsetAsync(b->d_vu, 0, S * sizeof(VuState), b->stream));
+    HIP_TRY(hipMalloc((void **)&b->d_nframes, S * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&b->d_sink, sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(b->d_sink, 0, sizeof(unsigned long long), b->stream));
+    if (d.flags & CMHIP_EQ) {
+        HIP_TRY(hipMalloc((void **)&b->d_eq, S * sizeof(EqParam)));
+        HIP_TRY(hipMalloc((void **)&b->d_eqstate, S * sizeof(EqState)));
+        HIP_TRY(hipMemsetAsync(b->d_eq, 0, S * sizeof(EqParam), b->stream));
+        HIP_TRY(hipMemsetAsync(b->d_eqstate, 0, S * sizeof(EqState), b->stream));
+        b->h_eq.assign(S, EqParam{});
+    }
+    HIP_TRY(hipHostMalloc((void **)&b->h_snap, S * sizeof(VuState), hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&b->snap_event, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void **)&b->h_stage, STAGE_SLOTS * STAGE_BYTES, hipHostMallocDefault));
+    for (unsigned i = 0; i < STAGE_SLOTS; i++)
+        HIP_TRY(hipEventCreateWithFlags(&b->stage_ev[i], hipEventDisableTiming));
+
+    b->h_param.assign(S, StreamParam{});
+    b->h_scale.assign(S, 0);
+    b->h_gain.assign(S * MAX_CH, 0);
+    for (size_t s = 0; s < S; s++) {
+        for (unsigned c = 0; c < MAX_CH; c++)
+            b->h_param[s].chmap[c] = (uint8_t)(c < d.channels ? c : 0);
+        rebuild_param(b, (unsigned)s);
+    }
+    const char *it = getenv("CMHIP_ITERS");
+    b->iters_override = it ? (unsigned)atoi(it) : 0;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
+{
+    if (!desc) {
+        fail(COOLMIC_ERROR_FAULT, "cmhip_batch_new: desc is NULL");
+        return nullptr;
+    }
+    if (desc->streams == 0 || desc->channels == 0 || desc->channels > MAX_CH ||
+        desc->max_frames == 0 || desc->rate == 0) {
+        fail(COOLMIC_ERROR_INVAL, "cmhip_batch_new: streams/channels/max_frames/rate out of range");
+        return nullptr;
+    }
+    if ((uint64_t)desc->max_frames * desc->channels >= (1ull << 31)) {
+        fail(COOLMIC_ERROR_INVAL, "cmhip_batch_new: slot larger than 2^31 samples");
+        return nullptr;
+    }
+    if ((desc->flags & CMHIP_EQ) && desc->channels != 1) {
+        fail(COOLMIC_ERROR_INVAL, "cmhip_batch_new: CMHIP_EQ needs a mono batch");
+        return nullptr;
+    }
+    if (!(desc->flags & (CMHIP_OUT_PCM | CMHIP_OUT_F32 | CMHIP_VU))) {
+        fail(COOLMIC_ERROR_INVAL, "cmhip_batch_new: no output requested");
+        return nullptr;
+    }
+    if (cmhip_device_count() <= desc->device || desc->device < 0) {
+        fail(COOLMIC_ERROR_NOSYS, "cmhip_batch_new: no HIP device %d (%d visible); there is no CPU path",
+             desc->device, cmhip_device_count());
+        return nullptr;
+    }
+    cmhip_batch_t *b = new cmhip_batch();
+    b->d = *desc;
+    b->stream = nullptr;
+    b->own_stream = false;
+    b->d_in = b->d_out = nullptr;
+    b->d_f32 = nullptr;
+    b->d_param = nullptr;
+    b->d_vu = nullptr;
+    b->d_nframes = nullptr;
+    b->d_eq = nullptr;
+    b->d_eqstate = nullptr;
+    b->d_sink = nullptr;
+    b->h_snap = nullptr;
+    b->h_stage = nullptr;
+    for (unsigned i = 0; i < STAGE_SLOTS; i++) {
+        b->stage_ev[i] = nullptr;
+        b->stage_busy[i] = false;
+    }
+    b->stage_next = 0;
+    b->snap_event = nullptr;
+    b->snap_pending = false;
+    b->param_dirty = true;
+    b->eq_dirty = false;
+    b->nsec = 0;
+    b->timing = false;
+    b->iters_override = 0;
+    if (batch_init(b) != COOLMIC_ERROR_NONE) {
+        cmhip_batch_free(b);
+        return nullptr;
+    }
+    return b;
+}
+
+// test hook: the division constants for a scale (host logic, needs no GPU)
+extern "C" void cmhip_test_magic(uint16_t scale, uint32_t *magic, uint32_t *shift)
+{
+    host_magic(scale, magic, shift);
+}
+
+// ---------------------------------------------------------------------------
+// parameters
+
+// ref: src/transform.c:195-222, per stream
+static int set_gain_one(cmhip_batch_t *b, unsigned int s, unsigned int channels, uint16_t scale,
+                        const uint16_t *gain)
+{
+    uint16_t *g = &b->h_gain[(size_t)s * MAX_CH];
+    const unsigned int own = b->d.channels;
+    if (!channels || !scale || !gain) {
+        b->h_scale[s] = 0;
+    } else if (channels == own) {
+        for (unsigned c = 0; c < own; c++)
+            g[c] = gain[c];
+        b->h_scale[s] = scale;
+    } else if (channels == 1) {
+        for (unsigned c = 0; c < own; c++)
+            g[c] = gain[0];
+        b->h_scale[s] = scale;
+    } else if (channels == 2 && own == 1) {
+        g[0] = (uint16_t)(((uint32_t)gain[0] + (uint32_t)gain[1]) / 2u);
+        b->h_scale[s] = scale;
+    } else {
+        return COOLMIC_ERROR_INVAL;
+    }
+    rebuild_param(b, s);
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_set_gain(cmhip_batch_t *b, long stream, unsigned int channels,
+                                    uint16_t scale, const uint16_t *gain)
+{
+    if (!b)
+        return fail(COOLMIC_ERROR_FAULT, "set_gain: batch is NULL");
+    if (stream >= (long)b->d.streams || stream < -1)
+        return fail(COOLMIC_ERROR_INVAL, "set_gain: stream %ld out of range", stream);
+    if (stream >= 0)
+        return set_gain_one(b, (unsigned)stream, channels, scale, gain);
+    int rc = COOLMIC_ERROR_NONE;
+    for (unsigned s = 0; s < b->d.streams && rc == COOLMIC_ERROR_NONE; s++)
+        rc = set_gain_one(b, s, channels, scale, gain);
+    return rc;
+}
+
+extern "C" int cmhip_batch_set_chmap(cmhip_batch_t *b, long stream, const uint8_t *map)
+{
+    if (!b)
+        return fail(COOLMIC_ERROR_FAULT, "set_chmap: batch is NULL");
+    if (stream >= (long)b->d.streams || stream < -1)
+        return fail(COOLMIC_ERROR_INVAL, "set_chmap: stream %ld out of range", stream);
+    if (map)
+        for (unsigned c = 0; c < b->d.channels; c++)
+            if (map[c] >= b->d.channels)
+                return fail(COOLMIC_ERROR_INVAL, "set_chmap: map[%u]=%u >= channels", c, map[c]);
+    const unsigned lo = stream < 0 ? 0 : (unsigned)stream;
+    const unsigned hi = stream < 0 ? b->d.streams : (unsigned)stream + 1;
+    for (unsigned s = lo; s < hi; s++) {
+        for (unsigned c = 0; c < b->d.channels; c++)
+            b->h_param[s].chmap[c] = map ? map[c] : (uint8_t)c;
+        rebuild_param(b, s);
+    }
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_set_eq(cmhip_batch_t *b, long stream, unsigned int nsec,
+                                  const float *coef)
+{
+    if (!b)
+        return fail(COOLMIC_ERROR_FAULT, "set_eq: batch is NULL");
+    if (!(b->d.flags & CMHIP_EQ))
+        return fail(COOLMIC_ERROR_INVAL, "set_eq: batch was created without CMHIP_EQ");
+    if (nsec > MAX_EQ || (nsec && !coef))
+        return fail(COOLMIC_ERROR_INVAL, "set_eq: at most %u sections", MAX_EQ);
+    if (stream >= (long)b->d.streams || stream < -1)
+        return fail(COOLMIC_ERROR_INVAL, "set_eq: stream %ld out of range", stream);
+    if (stream >= 0 && nsec != b->nsec)
+        return fail(COOLMIC_ERROR_INVAL,
+                    "set_eq: the section count is a batch property (%u); set it with stream -1",
+                    b->nsec);
+    const unsigned lo = stream < 0 ? 0 : (unsigned)stream;
+    const unsigned hi = stream < 0 ? b->d.streams : (unsigned)stream + 1;
+    for (unsigned s = lo; s < hi; s++) {
+        b->h_eq[s].nsec = nsec;
+        for (unsigned i = 0; i < nsec; i++)
+            for (unsigned j = 0; j < 5; j++)
+                b->h_eq[s].coef[i][j] = coef[i * 5 + j];
+    }
+    b->nsec = nsec;
+    b->eq_dirty = true;
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_eq_reset(cmhip_batch_t *b, long stream)
+{
+    if (!b || !(b->d.flags & CMHIP_EQ))
+        return fail(COOLMIC_ERROR_INVAL, "eq_reset: no EQ in this batch");
+    if (stream >= (long)b->d.streams || stream < -1)
+        return fail(COOLMIC_ERROR_INVAL, "eq_reset: stream %ld out of range", stream);
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    if (stream < 0)
+        HIP_TRY(hipMemsetAsync(b->d_eqstate, 0, b->d.streams * sizeof(EqState), b->stream));
+    else
+        HIP_TRY(hipMemsetAsync(b->d_eqstate + stream, 0, sizeof(EqState), b->stream));
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" void cmhip_design_biquad(int kind, double rate, double freq, double gain_db, double q,
+                                    float *coef)
+{
+    // RBJ audio-EQ-cookbook forms, evaluated in double and rounded to float once
+    const double A = pow(10., gain_db / 40.);
+    const double w0 = 2. * M_PI * freq / rate;
+    const double cw = cos(w0), sw = sin(w0);
+    double b0, b1, b2, a0, a1, a2;
+    if (kind == 1) {
+        const double alpha = sw / (2. * q);
+        b0 = 1. + alpha * A;
+        b1 = -2. * cw;
+        b2 = 1. - alpha * A;
+        a0 = 1. + alpha / A;
+        a1 = -2. * cw;
+        a2 = 1. - alpha / A;
+    } else {
+        const double alpha = sw / 2. * sqrt(2.);
+        const double k = 2. * sqrt(A) * alpha;
+        const double ap = A + 1., am = A - 1.;
+        if (kind == 0) {
+            b0 = A * (ap - am * cw + k);
+            b1 = 2. * A * (am - ap * cw);
+            b2 = A * (ap - am * cw - k);
+            a0 = ap + am * cw + k;
+            a1 = -2. * (am + ap * cw);
+            a2 = ap + am * cw - k;
+        } else {
+            b0 = A * (ap + am * cw + k);
+            b1 = -2. * A * (am + ap * cw);
+            b2 = A * (ap + am * cw - k);
+            a0 = ap - am * cw + k;
+            a1 = 2. * (am - ap * cw);
+            a2 = ap - am * cw - k;
+        }
+    }
+    coef[0] = (float)(b0 / a0);
+    coef[1] = (float)(b1 / a0);
+    coef[2] = (float)(b2 / a0);
+    coef[3] = (float)(a1 / a0);
+    coef[4] = (float)(a2 / a0);
+}
+
+// ---------------------------------------------------------------------------
+// geometry, transfers, generation
+
+extern "C" size_t cmhip_batch_stride(const cmhip_batch_t *b) { return b ? b->stride : 0; }
+extern "C" size_t cmhip_batch_max_frames(const cmhip_batch_t *b) { return b ? b->d.max_frames : 0; }
+extern "C" void *cmhip_batch_dev_in(cmhip_batch_t *b) { return b ? b->d_in : nullptr; }
+extern "C" void *cmhip_batch_dev_out(cmhip_batch_t *b) { return b ? b->d_out : nullptr; }
+extern "C" void *cmhip_batch_dev_f32(cmhip_batch_t *b) { return b ? b->d_f32 : nullptr; }
+extern "C" void *cmhip_batch_hip_stream(cmhip_batch_t *b) { return b ? (void *)b->stream : nullptr; }
+
+extern "C" int cmhip_batch_upload(cmhip_batch_t *b, unsigned int stream, const int16_t *pcm,
+                                  size_t frames)
+{
+    if (!b || !pcm)
+        return fail(COOLMIC_ERROR_FAULT, "upload: NULL argument");
+    if (stream >= b->d.streams || frames > b->d.max_frames)
+        return fail(COOLMIC_ERROR_INVAL, "upload: stream or frames out of range");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    const size_t bytes = frames * b->d.channels * sizeof(int16_t);
+    int16_t *dst = b->d_in + (size_t)stream * b->stride;
+    if (bytes == 0)
+        return COOLMIC_ERROR_NONE;
+    if (bytes <= STAGE_BYTES) {
+        // small blocks (the 1 KiB pulls of the per-stream stages): bounce through pinned
+        // memory so the caller may reuse its buffer as soon as we return
+        const unsigned slot = b->stage_next;
+        b->stage_next = (slot + 1) % STAGE_SLOTS;
+        if (b->stage_busy[slot])
+            HIP_TRY(hipEventSynchronize(b->stage_ev[slot]));
+        unsigned char *bounce = b->h_stage + (size_t)slot * STAGE_BYTES;
+        memcpy(bounce, pcm, bytes);
+        HIP_TRY(hipMemcpyAsync(dst, bounce, bytes, hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
+        b->stage_busy[slot] = true;
+    } else {
+        HIP_TRY(hipMemcpyAsync(dst, pcm, bytes, hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+    }
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_download(cmhip_batch_t *b, unsigned int stream, int16_t *pcm,
+                                    size_t frames)
+{
+    if (!b || !pcm)
+        return fail(COOLMIC_ERROR_FAULT, "download: NULL argument");
+    if (!b->d_out)
+        return fail(COOLMIC_ERROR_INVAL, "download: batch has no PCM output");
+    if (stream >= b->d.streams || frames > b->d.max_frames)
+        return fail(COOLMIC_ERROR_INVAL, "download: stream or frames out of range");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    HIP_TRY(hipMemcpyAsync(pcm, b->d_out + (size_t)stream * b->stride,
+                           frames * b->d.channels * sizeof(int16_t), hipMemcpyDeviceToHost,
+                           b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_download_input(cmhip_batch_t *b, unsigned int stream, int16_t *pcm,
+                                          size_t frames)
+{
+    if (!b || !pcm)
+        return fail(COOLMIC_ERROR_FAULT, "download_input: NULL argument");
+    if (stream >= b->d.streams || frames > b->d.max_frames)
+        return fail(COOLMIC_ERROR_INVAL, "download_input: stream or frames out of range");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    HIP_TRY(hipMemcpyAsync(pcm, b->d_in + (size_t)stream * b->stride,
+                           frames * b->d.channels * sizeof(int16_t), hipMemcpyDeviceToHost,
+                           b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_download_f32(cmhip_batch_t *b, unsigned int stream, unsigned int channel,
+                                        float *dst, size_t frames)
+{
+    if (!b || !dst)
+        return fail(COOLMIC_ERROR_FAULT, "download_f32: NULL argument");
+    if (!b->d_f32)
+        return fail(COOLMIC_ERROR_INVAL, "download_f32: batch has no float output");
+    if (stream >= b->d.streams || channel >= b->d.channels || frames > b->d.max_frames)
+        return fail(COOLMIC_ERROR_INVAL, "download_f32: argument out of range");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    HIP_TRY(hipMemcpyAsync(dst, b->d_f32 + ((size_t)stream * b->d.channels + channel) * b->plane,
+                           frames * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_generate(cmhip_batch_t *b, int mode, uint32_t seed, size_t frames,
+                                    uint64_t first_global, uint64_t global_step,
+                                    uint64_t frame_offset)
+{
+    if (!b)
+        return fail(COOLMIC_ERROR_FAULT, "generate: batch is NULL");
+    if (frames > b->d.max_frames || mode < 0 || mode > 2)
+        return fail(COOLMIC_ERROR_INVAL, "generate: frames or mode out of range");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    GenArgs g;
+    memset(&g, 0, sizeof(g));
+    g.dst = b->d_in;
+    g.streams = b->d.streams;
+    g.channels = b->d.channels;
+    g.frames = (uint32_t)frames;
+    g.stride = b->stride;
+    g.seed = seed;
+    g.first_global = first_global;
+    g.global_step = global_step;
+    g.frame_offset = frame_offset;
+    size_t n = 0;
+    if (coolmic_sine_period(48000, g.sine, &n) != COOLMIC_ERROR_NONE || n != 48)
+        return fail(COOLMIC_ERROR_GENERIC, "generate: sine table unavailable");
+    HIP_TRY(launch_generate(g, mode, b->stream));
+    return COOLMIC_ERROR_NONE;
+}
+
+// ---------------------------------------------------------------------------
+// the hot path
+
+static int flush_params(cmhip_batch_t *b)
+{
+    if (b->param_dirty) {
+        HIP_TRY(hipMemcpyAsync(b->d_param, b->h_param.data(), b->h_param.size() * sizeof(StreamParam),
+                               hipMemcpyHostToDevice, b->stream));
+        b->param_dirty = false;
+    }
+    if (b->eq_dirty) {
+        HIP_TRY(hipMemcpyAsync(b->d_eq, b->h_eq.data(), b->h_eq.size() * sizeof(EqParam),
+                               hipMemcpyHostToDevice, b->stream));
+        b->eq_dirty = false;
+    }
+    return COOLMIC_ERROR_NONE;
+}
+
+static void pick_chunks(const cmhip_batch_t *b, size_t frames, uint32_t *vec_per_chunk,
+                        uint32_t *chunks)
+{
+    // a wave walks 64*iters vectors; want >= 16 waves per SIMD over the chip
+    const uint64_t nvec = ((uint64_t)frames * b->d.channels + 7) / 8;
+    const uint64_t want = 256ull * 4 * 16;
+    unsigned iters = 32;
+    if (b->iters_override) {
+        iters = (b->iters_override + 3) / 4 * 4;
+    } else {
+        while (iters > 4 && (uint64_t)b->d.streams * ((nvec + 64ull * iters - 1) / (64ull * iters)) < want)
+            iters -= 4;
+    }
+    if (iters > 1024)
+        iters = 1024;
+    *vec_per_chunk = 64u * iters;
+    *chunks = (uint32_t)((nvec + *vec_per_chunk - 1) / *vec_per_chunk);
+    if (*chunks == 0)
+        *chunks = 1;
+}
+
+static EventPair take_events(cmhip_batch_t *b)
+{
+    EventPair e{};
+    if (!b->ev_free.empty()) {
+        e = b->ev_free.back();
+        b->ev_free.pop_back();
+    } else {
+        (void)hipEventCreate(&e.a);
+        (void)hipEventCreate(&e.b);
+    }
+    return e;
+}
+
+extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per_stream)
+{
+    if (!b)
+        return fail(COOLMIC_ERROR_FAULT, "run: batch is NULL");
+    if (frames > b->d.max_frames)
+        return fail(COOLMIC_ERROR_INVAL, "run: %zu frames exceed the slot capacity %zu", frames,
+                    b->d.max_frames);
+    if (frames == 0)
+        return COOLMIC_ERROR_NONE;
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    if (frames_per_stream) {
+        for (unsigned s = 0; s < b->d.streams; s++)
+            if (frames_per_stream[s] > frames)
+                return fail(COOLMIC_ERROR_INVAL, "run: frames_per_stream[%u] above frames", s);
+        HIP_TRY(hipMemcpyAsync(b->d_nframes, frames_per_stream, b->d.streams * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, b->stream));
+    }
+    if (flush_params(b))
+        return COOLMIC_ERROR_GENERIC;
+
+    const bool vu = (b->d.flags & CMHIP_VU) != 0;
+    EventPair ev{};
+    if (b->timing) {
+        ev = take_events(b);
+        HIP_TRY(hipEventRecord(ev.a, b->stream));
+    }
+    if (b->d.flags & CMHIP_EQ) {
+        EqArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = b->d_in;
+        a.out = (b->d.flags & CMHIP_OUT_PCM) ? b->d_out : nullptr;
+        a.f32 = b->d_f32;
+        a.param = b->d_param;
+        a.eq = b->d_eq;
+        a.state = b->d_eqstate;
+        a.vu = vu ? b->d_vu : nullptr;
+        a.nframes = frames_per_stream ? b->d_nframes : nullptr;
+        a.frames = (uint32_t)frames;
+        a.streams = b->d.streams;
+        a.nsec = b->nsec;
+        a.stride = b->stride;
+        a.plane = b->plane;
+        HIP_TRY(launch_eq(a, b->stream));
+    } else {
+        RunArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = b->d_in;
+        a.out = (b->d.flags & CMHIP_OUT_PCM) ? b->d_out : nullptr;
+        a.f32 = b->d_f32;
+        a.param = b->d_param;
+        a.vu = vu ? b->d_vu : nullptr;
+        a.nframes = frames_per_stream ? b->d_nframes : nullptr;
+        a.frames = (uint32_t)frames;
+        a.streams = b->d.streams;
+        a.channels = b->d.channels;
+        a.stride = b->stride;
+        a.plane = b->plane;
+        pick_chunks(b, frames, &a.vec_per_chunk, &a.chunks);
+        HIP_TRY(launch_run(a, b->stream));
+    }
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(ev.b, b->stream));
+        b->ev_used.push_back(ev);
+    }
+    if (vu)
+        HIP_TRY(launch_vu_advance(b->d_vu, frames_per_stream ? b->d_nframes : nullptr,
+                                  (uint32_t)frames, b->d.streams, b->d.channels, b->stream));
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_sync(cmhip_batch_t *b)
+{
+    if (!b)
+        return fail(COOLMIC_ERROR_FAULT, "sync: batch is NULL");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return COOLMIC_ERROR_NONE;
+}
+
+// ---------------------------------------------------------------------------
+// VU windows
+
+static int16_t key_peak(unsigned long long key)
+{
+    const int mag = (int)(key >> KEY_ABS_SHIFT);
+    return (int16_t)((key & 1ull) ? -mag : mag);
+}
+
+// ref: src/vumeter.c:203-205 -- integer mean first, then dB in double, capped at 0
+static double power_db(unsigned long long sum, unsigned long long count)
+{
+    double p = (double)(sum / count);
+    p = 20. * log10(sqrt(p) / 32768.);
+    return fmin(p, 0.);
+}
+
+static int finish_window(const cmhip_batch_t *b, const VuState &v, coolmic_vumeter_result_t *out)
+{
+    const unsigned C = b->d.channels;
+    const unsigned long long frames = v.samples / C;
+    if (frames == 0)
+        return COOLMIC_ERROR_INVAL;                      // ref: src/vumeter.c:198-199
+    memset(out, 0, sizeof(*out));
+    out->rate = b->d.rate;
+    out->channels = C;
+    out->frames = (size_t)frames;
+    unsigned long long all = 0, best = 0;
+    for (unsigned c = 0; c < C; c++) {
+        all += v.power[c];
+        out->channel_power[c] = power_db(v.power[c], frames);
+        out->channel_peak[c] = key_peak(v.key[c]);
+        if (v.key[c] > best)
+            best = v.key[c];
+    }
+    out->global_power = power_db(all, frames * C);
+    out->global_peak = key_peak(best);       // first max-|x| over all channels
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_vu_result(cmhip_batch_t *b, unsigned int stream,
+                                     coolmic_vumeter_result_t *out)
+{
+    if (!b || !out)
+        return fail(COOLMIC_ERROR_FAULT, "vu_result: NULL argument");
+    if (stream >= b->d.streams || !(b->d.flags & CMHIP_VU))
+        return fail(COOLMIC_ERROR_INVAL, "vu_result: stream out of range or batch without VU");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    VuState v;
+    HIP_TRY(hipMemcpyAsync(&v, b->d_vu + stream, sizeof(v), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    const int rc = finish_window(b, v, out);
+    if (rc == COOLMIC_ERROR_NONE)
+        HIP_TRY(hipMemsetAsync(b->d_vu + stream, 0, sizeof(VuState), b->stream));
+    return rc;
+}
+
+extern "C" int cmhip_batch_vu_snapshot(cmhip_batch_t *b)
+{
+    if (!b)
+        return fail(COOLMIC_ERROR_FAULT, "vu_snapshot: batch is NULL");
+    if (!(b->d.flags & CMHIP_VU))
+        return fail(COOLMIC_ERROR_INVAL, "vu_snapshot: batch without VU");
+    if (b->snap_pending)
+        return fail(COOLMIC_ERROR_BUSY, "vu_snapshot: previous snapshot not collected");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    const size_t bytes = b->d.streams * sizeof(VuState);
+    HIP_TRY(hipMemcpyAsync(b->h_snap, b->d_vu, bytes, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemsetAsync(b->d_vu, 0, bytes, b->stream));
+    HIP_TRY(hipEventRecord(b->snap_event, b->stream));
+    b->snap_pending = true;
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_vu_collect(cmhip_batch_t *b, coolmic_vumeter_result_t *out, int *rc)
+{
+    if (!b || !out)
+        return fail(COOLMIC_ERROR_FAULT, "vu_collect: NULL argument");
+    if (!b->snap_pending)
+        return fail(COOLMIC_ERROR_INVAL, "vu_collect: no snapshot pending");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    HIP_TRY(hipEventSynchronize(b->snap_event));
+    b->snap_pending = false;
+    for (unsigned s = 0; s < b->d.streams; s++) {
+        const int r = finish_window(b, b->h_snap[s], &out[s]);
+        if (rc)
+            rc[s] = r;
+    }
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_vu_results(cmhip_batch_t *b, coolmic_vumeter_result_t *out, int *rc)
+{
+    const int r = cmhip_batch_vu_snapshot(b);
+    if (r != COOLMIC_ERROR_NONE)
+        return r;
+    // NB: unlike the per-stream call this resets every window, also those with no frames
+    return cmhip_batch_vu_collect(b, out, rc);
+}
+
+extern "C" int cmhip_batch_vu_reset(cmhip_batch_t *b, long stream)
+{
+    if (!b)
+        return fail(COOLMIC_ERROR_FAULT, "vu_reset: batch is NULL");
+    if (stream >= (long)b->d.streams || stream < -1)
+        return fail(COOLMIC_ERROR_INVAL, "vu_reset: stream %ld out of range", stream);
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    if (stream < 0)
+        HIP_TRY(hipMemsetAsync(b->d_vu, 0, b->d.streams * sizeof(VuState), b->stream));
+    else
+        HIP_TRY(hipMemsetAsync(b->d_vu + stream, 0, sizeof(VuState), b->stream));
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_vu_raw(cmhip_batch_t *b, unsigned int stream, int64_t *power,
+                                  int16_t *peak, uint64_t *frames)
+{
+    if (!b)
+        return fail(COOLMIC_ERROR_FAULT, "vu_raw: batch is NULL");
+    if (stream >= b->d.streams)
+        return fail(COOLMIC_ERROR_INVAL, "vu_raw: stream out of range");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    VuState v;
+    HIP_TRY(hipMemcpyAsync(&v, b->d_vu + stream, sizeof(v), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    for (unsigned c = 0; c < MAX_CH; c++) {
+        if (power)
+            power[c] = (int64_t)v.power[c];
+        if (peak)
+            peak[c] = key_peak(v.key[c]);
+    }
+    if (frames)
+        *frames = v.samples / b->d.channels;
+    return COOLMIC_ERROR_NONE;
+}
+
+// ---------------------------------------------------------------------------
+// node-global VU
+
+extern "C" int cmhip_batch_vu_node_partial(cmhip_batch_t *b, void *dst_device,
+                                           uint64_t first_global, uint64_t global_step)
+{
+    if (!b || !dst_device)
+        return fail(COOLMIC_ERROR_FAULT, "vu_node_partial: NULL argument");
+    if (!(b->d.flags & CMHIP_VU))
+        return fail(COOLMIC_ERROR_INVAL, "vu_node_partial: batch without VU");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    HIP_TRY(launch_node_partial(b->d_vu, b->d.streams, b->d.channels, first_global, global_step,
+                                (long long *)dst_device, b->stream));
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_node_finish(const int64_t *w, unsigned int channels, unsigned int rate,
+                                 coolmic_vumeter_result_t *out)
+{
+    if (!w || !out)
+        return fail(COOLMIC_ERROR_FAULT, "node_finish: NULL argument");
+    if (channels == 0 || channels > MAX_CH)
+        return fail(COOLMIC_ERROR_INVAL, "node_finish: channels out of range");
+    const unsigned long long frames = (unsigned long long)w[MAX_CH];
+    if (frames == 0)
+        return COOLMIC_ERROR_INVAL;
+    memset(out, 0, sizeof(*out));
+    out->rate = rate;
+    out->channels = channels;
+    out->frames = (size_t)frames;
+    unsigned long long all = 0;
+    for (unsigned c = 0; c < channels; c++) {
+        const unsigned long long k = (unsigned long long)w[MAX_CH + 1 + c];
+        all += (unsigned long long)w[c];
+        out->channel_power[c] = power_db((unsigned long long)w[c], frames);
+        const int mag = (int)(k >> 46);
+        out->channel_peak[c] = (int16_t)((k & 1ull) ? -mag : mag);
+    }
+    const unsigned long long g = (unsigned long long)w[2 * MAX_CH + 1];
+    const int gm = (int)(g >> 46);
+    out->global_peak = (int16_t)((g & 1ull) ? -gm : gm);
+    out->global_power = power_db(all, frames * channels);
+    return COOLMIC_ERROR_NONE;
+}
+
+// ---------------------------------------------------------------------------
+// measurement
+
+extern "C" int cmhip_batch_timing(cmhip_batch_t *b, int enable)
+{
+    if (!b)
+        return fail(COOLMIC_ERROR_FAULT, "timing: batch is NULL");
+    b->timing = enable != 0;
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_timing_read(cmhip_batch_t *b, double *kernel_ms, unsigned int *launches)
+{
+    if (!b)
+        return fail(COOLMIC_ERROR_FAULT, "timing_read: batch is NULL");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    double ms = 0.;
+    for (auto &e : b->ev_used) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, e.a, e.b));
+        ms += t;
+    }
+    if (kernel_ms)
+        *kernel_ms = ms;
+    if (launches)
+        *launches = (unsigned)b->ev_used.size();
+    b->ev_free.insert(b->ev_free.end(), b->ev_used.begin(), b->ev_used.end());
+    b->ev_used.clear();
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" double cmhip_batch_ceiling(cmhip_batch_t *b, int mode, size_t frames, int iters)
+{
+    if (!b || iters <= 0 || frames > b->d.max_frames || (mode == 1 && (!b->d_out || b->d_out == b->d_in))) {
+        fail(COOLMIC_ERROR_INVAL, "ceiling: bad arguments (copy needs a separate PCM output)");
+        return -1.;
+    }
+    if (hipSetDevice(b->d.device) != hipSuccess)
+        return -1.;
+    // whole slots, so that the byte count is exact and contiguous
+    (void)frames;
+    const size_t bytes = (size_t)b->d.streams * b->stride * sizeof(int16_t);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return -1.;
+    for (int i = 0; i < 2; i++)
+        (void)launch_ceiling(mode, b->d_in, b->d_out, bytes, b->d_sink, b->stream);
+    (void)hipEventRecord(e0, b->stream);
+    for (int i = 0; i < iters; i++)
+        (void)launch_ceiling(mode, b->d_in, b->d_out, bytes, b->d_sink, b->stream);
+    (void)hipEventRecord(e1, b->stream);
+    float ms = 0.f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+        fail(COOLMIC_ERROR_GENERIC, "ceiling: event timing failed");
+        return -1.;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const double moved = (double)bytes * (mode == 1 ? 2. : 1.) * iters;
+    return moved / (ms * 1e-3) / 1e9;
+}

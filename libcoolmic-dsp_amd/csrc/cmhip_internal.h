@@ -1,0 +1,105 @@
+// cmhip_internal.h -- device-side records and launcher prototypes shared by
+// cmhip_kernels.hip (the gfx950 kernels) and cmhip_batch.hip (the engine).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cmhip {
+
+constexpr unsigned MAX_CH = 16;
+constexpr unsigned MAX_EQ = 4;
+
+// Per-stream transform parameters, rebuilt on the host whenever a setter runs.
+// Division by `scale` is done on magnitudes: with n2 = |x| * gain2[c] (= 2*|x|*gain,
+// below 2^32) the quotient floor(|x|*gain/scale) is mulhi(n2, magic) >> shift, exact
+// for every |x| <= 32768, gain <= 65535, scale in 1..65535 (host_magic() proves the
+// bound).  A disabled gain (scale 0 in the reference, ref: src/transform.c:107-108)
+// is stored as gain 1 / scale 1, which is the identity through the same code.
+struct StreamParam {
+    uint32_t magic;            // ceil(2^(31+shift) / scale)
+    uint32_t shift;            // ceil(log2(scale))
+    uint32_t perm2;            // stereo channel map as a v_perm_b32 selector
+    uint32_t map_identity;     // 1 when chmap is the identity
+    uint32_t gain2[MAX_CH];    // 2 * gain[c]
+    uint8_t  chmap[MAX_CH];    // out channel c reads in channel chmap[c]
+};
+
+// Per-stream VU window, all 64-bit so that every update is an integer atomic
+// (add / max are associative and commutative: results do not depend on the order
+// in which waves arrive).
+//   key = |peak| << 47 | (~sample_index & (2^46-1)) << 1 | negative
+// sample_index counts interleaved samples since the window opened, so the largest
+// key is the largest magnitude and, among equals, the earliest sample: the
+// reference's strict-greater update (ref: src/vumeter.c:163-168).
+struct VuState {
+    unsigned long long power[MAX_CH];
+    unsigned long long key[MAX_CH];
+    unsigned long long samples;          // interleaved samples accounted so far
+};
+
+constexpr int      KEY_ABS_SHIFT = 47;
+constexpr uint64_t KEY_IDX_MASK  = (1ull << 46) - 1;
+
+struct EqParam {
+    uint32_t nsec;
+    float    coef[MAX_EQ][5];  // b0 b1 b2 a1 a2
+};
+struct EqState {
+    float s[MAX_EQ][4];        // x1 x2 y1 y2 per section
+};
+
+struct RunArgs {
+    const int16_t *in;
+    int16_t       *out;            // may equal in; nullptr: PCM not written
+    float         *f32;            // planar float output or nullptr
+    const StreamParam *param;
+    VuState       *vu;             // nullptr: no VU
+    const uint32_t *nframes;       // per-stream frame counts or nullptr
+    uint32_t       frames;         // uniform count when nframes == nullptr
+    uint32_t       streams;
+    uint32_t       channels;
+    uint64_t       stride;         // samples between stream slots (multiple of 8)
+    uint64_t       plane;          // floats between planes of the f32 output
+    uint32_t       vec_per_chunk;  // 16-byte vectors one wave walks (multiple of 256)
+    uint32_t       chunks;         // wave-chunks per stream
+};
+
+struct EqArgs {
+    const int16_t *in;
+    int16_t       *out;            // int16 result or nullptr
+    float         *f32;            // float result or nullptr
+    const StreamParam *param;
+    const EqParam *eq;
+    EqState       *state;
+    VuState       *vu;             // VU of the int16 result, or nullptr
+    const uint32_t *nframes;
+    uint32_t       frames;
+    uint32_t       streams;
+    uint32_t       nsec;           // biquad sections, same for every stream of the batch
+    uint64_t       stride;
+    uint64_t       plane;
+};
+
+struct GenArgs {
+    int16_t *dst;
+    uint32_t streams, channels, frames;
+    uint64_t stride;
+    uint32_t seed;
+    uint64_t first_global, global_step, frame_offset;
+    int16_t  sine[48];
+};
+
+// launchers (cmhip_kernels.hip)
+hipError_t launch_run(const RunArgs &a, hipStream_t st);
+hipError_t launch_vu_advance(VuState *vu, const uint32_t *nframes, uint32_t frames,
+                             uint32_t streams, uint32_t channels, hipStream_t st);
+hipError_t launch_eq(const EqArgs &a, hipStream_t st);
+hipError_t launch_generate(const GenArgs &a, int mode, hipStream_t st);
+hipError_t launch_node_partial(const VuState *vu, uint32_t streams, uint32_t channels,
+                               uint64_t first_global, uint64_t global_step, long long *dst,
+                               hipStream_t st);
+hipError_t launch_ceiling(int mode, const void *src, void *dst, size_t bytes,
+                          unsigned long long *sink, hipStream_t st);
+
+}  // namespace cmhip

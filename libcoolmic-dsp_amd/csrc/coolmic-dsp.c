@@ -1,0 +1,57 @@
+/* coolmic-dsp.c -- error texts and the feature string
+ * (contract: <coolmic-dsp/coolmic-dsp.h>; ref: src/coolmic-dsp.c:30-112). */
+#include "host_internal.h"
+
+#include <string.h>
+
+const char *coolmic_error2string(const int error)
+{
+    switch (error) {
+    case COOLMIC_ERROR_NONE:        return "No error";
+    case COOLMIC_ERROR_GENERIC:     return "Generic, unknown error";
+    case COOLMIC_ERROR_NOSYS:       return "Function not implemented";
+    case COOLMIC_ERROR_FAULT:       return "Bad address";
+    case COOLMIC_ERROR_INVAL:       return "Invalid argument";
+    case COOLMIC_ERROR_NOMEM:       return "Not enough space";
+    case COOLMIC_ERROR_BUSY:        return "Device or resource busy";
+    case COOLMIC_ERROR_PERM:        return "Operation not permitted";
+    case COOLMIC_ERROR_CONNREFUSED: return "Connection refused";
+    case COOLMIC_ERROR_CONNECTED:   return "Connected.";
+    case COOLMIC_ERROR_UNCONNECTED: return "Unconnected.";
+    case COOLMIC_ERROR_NOTLS:       return "TLS requested but not supported by peer";
+    case COOLMIC_ERROR_TLSBADCERT:
+        return "TLS connection can not be established because of bad certificate";
+    case COOLMIC_ERROR_BADRQC:      return "Invalid request code";
+    case COOLMIC_ERROR_RETRY:       return "Retry last action";
+    }
+    return "(unknown)";
+}
+
+const char *coolmic_features(void)
+{
+    return "features " COOLMIC_FEATURE_DRIVER_NULL " " COOLMIC_FEATURE_DRIVER_SINE
+           " " COOLMIC_FEATURE_ACCEL_HIP;
+}
+
+/* whole-word match inside the space separated list */
+int coolmic_feature_check(const char *feature)
+{
+    const char *list = coolmic_features();
+    size_t want;
+
+    if (feature == NULL)
+        return COOLMIC_ERROR_FAULT;
+    if (*feature == 0)
+        return COOLMIC_ERROR_INVAL;
+    want = strlen(feature);
+    while (*list) {
+        const char *end = strchr(list, ' ');
+        size_t len = end ? (size_t)(end - list) : strlen(list);
+        if (len == want && memcmp(list, feature, want) == 0)
+            return 1;
+        if (end == NULL)
+            break;
+        list = end + 1;
+    }
+    return 0;
+}

@@ -1,0 +1,33 @@
+/* host_internal.h -- declarations shared by the host-side C files of
+ * libcoolmic-dsp-hip.so (not installed, not part of the public ABI). */
+#ifndef COOLMIC_HOST_INTERNAL_H
+#define COOLMIC_HOST_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <sys/types.h>
+
+#include <coolmic-dsp/coolmic-dsp.h>
+#include <coolmic-dsp/iohandle.h>
+#include <coolmic-dsp/logging.h>
+#include <coolmic-dsp/ro-compat.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* one period of the 1 kHz test tone at `rate` (ref: src/snddev_sine.c:36-99,184):
+ * rate/1000 samples, amplitude 32766; COOLMIC_ERROR_NOSYS for unsupported rates */
+int coolmic_sine_period(uint_least32_t rate, int16_t *table, size_t *samples);
+
+/* HIP device the per-object (non-batch) stages run on: $COOLMIC_HIP_DEVICE or 0 */
+int coolmic_hip_default_device(void);
+
+/* access for stages that want to look through a transform's handle (fusion) */
+struct coolmic_transform;
+struct coolmic_transform *coolmic_iohandle_as_transform(coolmic_iohandle_t *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

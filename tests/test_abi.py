@@ -1,0 +1,94 @@
+"""CPU: the C-ABI library loads and exports every function include/*.h declares.
+No compute calls here (there is no GPU on this box)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADERS = [
+    "include/coolmic_hip.h",
+    "include/coolmic-dsp/ro-compat.h",
+    "include/coolmic-dsp/coolmic-dsp.h",
+    "include/coolmic-dsp/logging.h",
+    "include/coolmic-dsp/iohandle.h",
+    "include/coolmic-dsp/transform.h",
+    "include/coolmic-dsp/vumeter.h",
+    "include/coolmic-dsp/snddev.h",
+]
+DECL = re.compile(r"\b((?:cmhip|coolmic)_[a-z0-9_]+)\s*\(")
+
+
+def _declared(path):
+    text = open(os.path.join(ROOT, path)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)           # comments
+    text = re.sub(r"^\s*#\s*define[^\n]*(\\\n[^\n]*)*", "", text, flags=re.M)  # macros
+    names = set()
+    for m in DECL.finditer(text):
+        n = m.group(1)
+        if n.endswith("_t"):
+            continue
+        names.add(n)
+    return names
+
+
+def test_headers_compile_as_c_and_cxx(tmp_path):
+    import subprocess
+    src = "\n".join('#include <%s>' % h.split("include/", 1)[1] for h in HEADERS) + "\nint main(void){return 0;}\n"
+    for comp, ext, std in (("gcc", "c", "-std=gnu11"), ("g++", "cpp", "-std=c++17")):
+        f = tmp_path / ("t." + ext)
+        f.write_text(src)
+        subprocess.run([comp, std, "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "include"), str(f)], check=True)
+
+
+def test_every_declared_symbol_is_exported(cm):
+    declared = set()
+    for h in HEADERS:
+        declared |= _declared(h)
+    assert len(declared) > 50
+    missing = [n for n in sorted(declared) if not hasattr(cm.lib, n)]
+    assert not missing, missing
+    # and the Python mirror knows each of them
+    unbound = [n for n in sorted(declared) if n not in cm.SIGNATURES]
+    assert not unbound, unbound
+
+
+def test_result_struct_layout_matches_reference(cm):
+    """coolmic_vumeter_result_t is 192 bytes on LP64 with the offsets SURVEY 8(a) a9 lists"""
+    import ctypes as C
+    R = cm.VuResult
+    assert C.sizeof(R) == 192
+    offs = {n: getattr(R, n).offset for n, _ in R._fields_}
+    assert offs == {"rate": 0, "channels": 4, "frames": 8, "global_peak": 16, "global_power": 24,
+                    "channel_peak": 32, "channel_power": 64}
+
+
+def test_library_reports_itself(cm):
+    assert b"gfx950" in cm.lib.cmhip_version()
+    assert cm.lib.coolmic_feature_check(b"accel:hip/gfx950") == 1
+    assert cm.lib.coolmic_feature_check(b"driver:sine") == 1
+    assert cm.lib.coolmic_feature_check(b"driver:si") == 0
+    assert cm.lib.coolmic_feature_check(b"encode:ogg/vorbis") == 0
+    assert cm.lib.coolmic_feature_check(None) == cm.ERROR_FAULT
+    assert cm.lib.coolmic_feature_check(b"") == cm.ERROR_INVAL
+    assert cm.lib.coolmic_error2string(-10) == b"Invalid argument"
+    assert cm.lib.coolmic_error2string(-9) == b"Bad address"
+    assert cm.lib.coolmic_error2string(12345) == b"(unknown)"
+
+
+def test_no_oracle_in_the_product():
+    """the product must not reach into oracle/ (nor carry a CPU fallback)"""
+    pkg = os.path.join(ROOT, "libcoolmic-dsp_amd")
+    for base, _dirs, files in os.walk(pkg):
+        if os.sep + "build" in base or os.sep + "lib" in base:
+            continue
+        for f in files:
+            if f.endswith((".c", ".h", ".hip", ".py")) or f == "Makefile":
+                text = open(os.path.join(base, f), errors="replace").read()
+                assert "oracle" not in text.lower() or f == "sine_table.c" or f == "__init__.py", \
+                    os.path.join(base, f)
+    import subprocess
+    so = os.path.join(pkg, "lib", "libcoolmic-dsp-hip.so")
+    deps = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
+    assert "oracle" not in deps

@@ -1,0 +1,131 @@
+"""The per-stream operator API (coolmic_* names of the reference) running on the GPU:
+snddev -> transform -> vumeter wired through coolmic_iohandle_t exactly as
+src/simple.c:198-229 wires them, checked against SURVEY 8(c) and the oracle."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle_ffi as of
+
+pytestmark = pytest.mark.gpu
+
+
+def _pow(x):
+    return -math.inf if x == "-inf" else float(x)
+
+
+def _chain(cm, src_handle, channels, rate=48000):
+    tr = cm.Transform(rate, channels)
+    assert tr.attach(src_handle) == 0
+    src_handle.unref()                       # attach-then-unref idiom (ref: src/simple.c:212-229)
+    h = tr.get_iohandle()
+    vu = cm.Vumeter(rate, channels)
+    assert vu.attach(h) == 0
+    return tr, h, vu
+
+
+def test_config1_sine_chain_G1_G2_G3(gpu, golden):
+    cm = gpu
+    dev = cm.Snddev("sine", 48000, 1)
+    tr, h, vu = _chain(cm, dev.get_iohandle(), 1)
+    dev.unref()
+    for name in ("G1", "G2", "G3"):
+        case = golden["cases"][name]
+        g = case["gain"]
+        assert tr.set_master_gain(g["channels"], g["scale"], g["gain"]) == 0
+        for _ in range(case["reads"]):
+            assert vu.read(-1) == 1024
+        rc, r = vu.result()
+        assert rc == 0
+        exp = case["vu"]
+        assert r.frames == exp["frames"] and r.global_peak == exp["global_peak"]
+        assert r.global_power == exp["global_power"]
+        assert r.rate == 48000 and r.channels == 1
+    rc, _ = vu.result()
+    assert rc == cm.ERROR_INVAL
+    h.unref(); vu.unref(); tr.unref()
+
+
+def test_null_chain_G5(gpu, golden):
+    cm = gpu
+    dev = cm.Snddev("null", 48000, 2)
+    vu = cm.Vumeter(48000, 2)
+    h = dev.get_iohandle()
+    assert vu.attach(h) == 0
+    h.unref(); dev.unref()
+    assert vu.read(-1) == 1024
+    rc, r = vu.result()
+    assert rc == 0 and r.frames == 256 and r.global_peak == 0
+    assert r.global_power == -math.inf and r.channel_power[1] == -math.inf
+    vu.unref()
+
+
+@pytest.mark.parametrize("name", ["K1", "K2", "K3", "K4", "K5", "K9"])
+def test_known_answers_through_handles(gpu, golden, name):
+    cm = gpu
+    case = golden["cases"][name]
+    x = np.array(golden[case["input"]], dtype=np.int16)
+    tr, h, vu = _chain(cm, cm.IoHandle.from_bytes(x.tobytes()), case["channels"])
+    g = case["gain"]
+    assert tr.set_master_gain(g["channels"], g["scale"], g["gain"]) == 0
+    n, data = h.read(x.nbytes)
+    assert n == x.nbytes and np.frombuffer(data, np.int16).tolist() == case["pcm"]
+    # same data again through the meter
+    tr2, h2, vu2 = _chain(cm, cm.IoHandle.from_bytes(x.tobytes()), case["channels"])
+    tr2.set_master_gain(g["channels"], g["scale"], g["gain"])
+    assert vu2.read(-1) == x.nbytes
+    rc, r = vu2.result()
+    exp = case["vu"]
+    assert rc == 0 and r.global_power == _pow(exp["global_power"])
+    if "global_peak" in exp:
+        assert r.global_peak == exp["global_peak"]
+    for i, p in enumerate(exp.get("channel_peak", [])):
+        assert r.channel_peak[i] == p
+    for i, p in enumerate(exp.get("channel_power", [])):
+        assert r.channel_power[i] == _pow(p)
+    for o in (h, vu, tr, h2, vu2, tr2):
+        o.unref()
+
+
+def test_K6_K7_K8_framing(gpu, golden):
+    cm = gpu
+    x = np.array(golden["k_input_stereo"], dtype=np.int16)
+    tr, h, vu = _chain(cm, cm.IoHandle.from_bytes(x.tobytes()), 2)
+    assert tr.set_master_gain(3, 1000, [1, 2, 3]) == -10           # K6
+    assert tr.set_master_gain(2, 1000, [1000, 1000]) == 0
+    n, data = h.read(7)                                            # K7
+    assert n == 4 and np.frombuffer(data, np.int16).tolist() == [5, -7] and h.eof() == 0
+    for o in (h, vu, tr):
+        o.unref()
+    tr, h, vu = _chain(cm, cm.IoHandle.from_bytes(x.tobytes(), chunk=3), 2)   # K8
+    assert tr.set_master_gain(2, 1000, [1000, 1000]) == 0
+    n, data = h.read(16)
+    assert n == 16 and np.frombuffer(data, np.int16).tolist() == x.tolist()
+    for o in (h, vu, tr):
+        o.unref()
+
+
+def test_chain_matches_oracle_on_noise_with_map(gpu, oracle):
+    cm = gpu
+    C, frames = 2, 20000
+    x = oracle.lcg(2024, frames * C)
+    tr, h, vu = _chain(cm, cm.IoHandle.from_bytes(x.tobytes(), chunk=1000), C)
+    assert tr.set_master_gain(2, 1000, [750, 1250]) == 0
+    assert tr.set_channel_map([1, 0]) == 0
+    total = 0
+    while True:
+        n = vu.read(-1)
+        if n <= 0:
+            break
+        total += n
+    assert total == x.nbytes
+    rc, r = vu.result()
+    _, g = oracle.gain(C, 2, 1000, [750, 1250])
+    want = oracle.gain_apply(g, oracle.chmap([1, 0], x, C), C)
+    v = oracle.vu_new(C)
+    oracle.vu_accumulate(v, want)
+    _, ro = oracle.vu_result(v)
+    assert rc == 0 and r.as_dict() == of.vu_result_dict(ro)
+    for o in (h, vu, tr):
+        o.unref()

@@ -1,0 +1,99 @@
+"""GPU parity for the EQ path (BASELINE config 3): int16 -> gain -> x/32768.f -> 3 biquads
+-> float / int16 (+VU).  PARITY UNPINNED against the reference (it has no filter code);
+the oracle's Direct-Form-I fmaf order is the specification and the bar is bit-equal
+floats (both sides are built with -ffp-contract=off and use correctly rounded fma)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle_ffi as of
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_eq(oracle, coef, nsec, gain_args, blocks):
+    q = (of.Biquad * max(nsec, 1))()
+    for i in range(nsec):
+        q[i].b0, q[i].b1, q[i].b2, q[i].a1, q[i].a2 = [float(v) for v in coef[5 * i:5 * i + 5]]
+    g = None
+    if gain_args is not None:
+        rc, g = oracle.gain(1, *gain_args)
+        assert rc == 0
+    st = np.zeros(4 * max(nsec, 1), dtype=np.float32)
+    outs = []
+    for blk in blocks:
+        outs.append(oracle.eq_run_mono(g, q, nsec, st, blk))
+    return outs
+
+
+def test_design_matches_oracle_design(gpu, oracle):
+    cm = gpu
+    q = oracle.eq3(48000.0)
+    want = np.array([[q[i].b0, q[i].b1, q[i].b2, q[i].a1, q[i].a2] for i in range(3)],
+                    dtype=np.float32).reshape(-1)
+    assert np.array_equal(cm.eq3(48000.0).view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("nsec", [0, 1, 3, 4])
+def test_eq_bit_exact_with_state_carry(gpu, oracle, nsec):
+    cm = gpu
+    rng = np.random.default_rng(7 + nsec)
+    S, T = 70, 700                       # more than one 64-stream tile, ragged tiles
+    coef3 = cm.eq3(48000.0)
+    coef = np.concatenate([coef3, cm.design_biquad(1, 48000.0, 3000.0, 4.0, 2.0)])[: 5 * nsec]
+    b = cm.Batch(S, 1, T, flags=cm.EQ | cm.OUT_F32 | cm.OUT_PCM | cm.VU)
+    assert b.set_eq(-1, coef) == 0
+    gains = []
+    for s in range(S):
+        ga = None if s % 3 == 0 else (1, 1000, [int(rng.integers(200, 2500))])
+        if ga:
+            assert b.set_gain(s, *ga) == 0
+        gains.append(ga)
+    lens1 = [int(v) for v in rng.integers(0, T + 1, S)]
+    lens1[0], lens1[1], lens1[2] = T, 0, 1
+    lens2 = [int(v) for v in rng.integers(0, T + 1, S)]
+    blocks = [[rng.integers(-32768, 32768, n).astype(np.int16) for n in (lens1[s], lens2[s])]
+              for s in range(S)]
+    got = [[None, None] for _ in range(S)]
+    for k, lens in enumerate((lens1, lens2)):
+        for s in range(S):
+            if lens[s]:
+                b.upload(s, blocks[s][k])
+        b.run(T, frames_per_stream=lens)
+        for s in range(S):
+            got[s][k] = (b.download_f32(s, 0, lens[s]), b.download(s, lens[s]))
+    for s in range(S):
+        want = _oracle_eq(oracle, coef, nsec, gains[s], blocks[s])
+        v = oracle.vu_new(1)
+        for k in range(2):
+            wf, wi = want[k]
+            gf, gi = got[s][k]
+            assert np.array_equal(gf.view(np.uint32), wf.view(np.uint32)), (nsec, s, k)
+            assert np.array_equal(gi, wi), (nsec, s, k)
+            oracle.vu_accumulate(v, wi)
+        rc_o, r_o = oracle.vu_result(v)
+        rc_g, r_g = b.vu_result(s)
+        assert rc_g == rc_o, (nsec, s)
+        if rc_o == 0:
+            assert r_g.as_dict() == of.vu_result_dict(r_o), (nsec, s)
+    b.close()
+
+
+def test_eq_config3_shape_sampled(gpu, oracle):
+    """BASELINE config 3 shape (8192 mono streams) at a block the oracle finishes quickly;
+    sampled streams compared bit for bit, float output only"""
+    cm = gpu
+    S, T = 8192, 2048
+    coef = cm.eq3(48000.0)
+    b = cm.Batch(S, 1, T, flags=cm.EQ | cm.OUT_F32)
+    assert b.set_eq(-1, coef) == 0
+    assert b.set_gain(-1, 1, 1000, [900]) == 0
+    b.generate(cm.GEN_NOISE, 12345, T)
+    b.run(T)
+    for s in (0, 63, 64, 4097, 8191):
+        x = oracle.lcg(12345 + s, T)
+        (wf, _), = _oracle_eq(oracle, coef, 3, (1, 1000, [900]), [x])
+        gf = b.download_f32(s, 0, T)
+        assert np.array_equal(gf.view(np.uint32), wf.view(np.uint32)), s
+    b.close()

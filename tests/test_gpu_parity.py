@@ -1,0 +1,434 @@
+"""GPU parity: the HIP path (through the C ABI of include/coolmic_hip.h) against the CPU
+oracle on the same seeded inputs, and against the SURVEY 8(c) golden vectors.
+
+Bar: bit-exact for int16 PCM, VU accumulators and peaks; dB values bit-equal doubles
+(they are finished on the host with the reference's own formula).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle_ffi as of
+
+pytestmark = pytest.mark.gpu
+
+
+def _pow(x):
+    return -math.inf if x == "-inf" else float(x)
+
+
+def _oracle_block(orc, pcm, C, gain_args, cmap):
+    """reference result for one block: (pcm_out, vu_dict or None)"""
+    x = np.asarray(pcm, dtype=np.int16)
+    if cmap is not None:
+        x = orc.chmap(cmap, x, C)
+    rc, g = orc.gain(C, *gain_args) if gain_args is not None else (0, of.Gain())
+    assert rc == 0
+    y = orc.gain_apply(g, x, C)
+    return y
+
+
+def _oracle_vu(orc, blocks, C):
+    v = orc.vu_new(C)
+    for blk in blocks:
+        orc.vu_accumulate(v, blk)
+    rc, r = orc.vu_result(v)
+    return rc, r
+
+
+def _rand_pcm(rng, n, kind):
+    if kind == "full":
+        return rng.integers(-32768, 32768, size=n, dtype=np.int64).astype(np.int16)
+    if kind == "edges":
+        return rng.choice(np.array([-32768, -32767, -1, 0, 1, 32766, 32767], dtype=np.int16), size=n)
+    if kind == "small":
+        return rng.integers(-5, 6, size=n, dtype=np.int64).astype(np.int16)
+    raise ValueError(kind)
+
+
+# ---------------------------------------------------------------------------
+
+
+def test_golden_known_answers_through_batch(gpu, golden):
+    cm = gpu
+    for name in ("K1", "K2", "K3", "K4", "K5", "K9"):
+        case = golden["cases"][name]
+        x = np.array(golden[case["input"]], dtype=np.int16)
+        C = case["channels"]
+        b = cm.Batch(1, C, 64, flags=cm.OUT_PCM | cm.VU)
+        g = case["gain"]
+        assert b.set_gain(0, g["channels"], g["scale"], g["gain"]) == 0
+        b.upload(0, x)
+        b.run(x.size // C)
+        assert b.download(0, x.size // C).tolist() == case["pcm"], name
+        rc, r = b.vu_result(0)
+        assert rc == 0
+        exp = case["vu"]
+        if "frames" in exp:
+            assert r.frames == exp["frames"]
+        if "global_peak" in exp:
+            assert r.global_peak == exp["global_peak"], name
+        assert r.global_power == _pow(exp["global_power"]), name
+        for i, p in enumerate(exp.get("channel_peak", [])):
+            assert r.channel_peak[i] == p
+        for i, p in enumerate(exp.get("channel_power", [])):
+            assert r.channel_power[i] == _pow(p)
+        # a second result without new frames is INVAL (ref: src/vumeter.c:198-199)
+        rc2, _ = b.vu_result(0)
+        assert rc2 == cm.ERROR_INVAL
+        b.close()
+
+
+def test_golden_K6_invalid_gain_shape(gpu, golden):
+    cm = gpu
+    case = golden["cases"]["K6"]
+    b = cm.Batch(1, 2, 64, flags=cm.OUT_PCM)
+    assert b.set_gain(0, 3, 1000, [1, 2, 3]) == case["set_gain_rc"]
+    x = np.array(golden[case["input"]], dtype=np.int16)
+    b.upload(0, x)
+    b.run(4)
+    assert b.download(0, 4).tolist() == case["pcm"]
+    b.close()
+
+
+def test_golden_G4_and_sine_G1_G2_G3(gpu, golden, oracle):
+    cm = gpu
+    # G4: stereo LCG, gains {750,1250}/1000, 48128 frames
+    case = golden["cases"]["G4"]
+    b = cm.Batch(1, 2, case["frames"], flags=cm.VU)
+    assert b.set_gain(0, 2, 1000, [750, 1250]) == 0
+    b.generate(cm.GEN_NOISE, case["seed"], case["frames"])
+    b.run(case["frames"])
+    rc, r = b.vu_result(0)
+    exp = case["vu"]
+    assert rc == 0 and r.frames == exp["frames"] and r.global_peak == exp["global_peak"]
+    assert r.global_power == exp["global_power"]
+    assert [r.channel_peak[i] for i in range(2)] == exp["channel_peak"]
+    assert [r.channel_power[i] for i in range(2)] == exp["channel_power"]
+    b.close()
+
+    # G1..G3: the sine source's stream, cut where the reference chain cut it
+    g1, g2, g3 = (golden["cases"][k] for k in ("G1", "G2", "G3"))
+    n1 = g1["vu"]["frames"]
+    b = cm.Batch(1, 1, n1, flags=cm.VU)
+    b.generate(cm.GEN_SINE, 0, n1)
+    assert b.set_gain(0, 1, 1000, [1000]) == 0
+    b.run(n1)
+    rc, r = b.vu_result(0)
+    assert rc == 0 and r.frames == n1 and r.global_peak == g1["vu"]["global_peak"]
+    assert r.global_power == g1["vu"]["global_power"] == r.channel_power[0]
+    pos = n1
+    for case, gain in ((g2, 500), (g3, 2000)):
+        b.generate(cm.GEN_SINE, 0, 512, frame_offset=pos)
+        assert b.set_gain(0, 1, 1000, [gain]) == 0
+        b.run(512)
+        rc, r = b.vu_result(0)
+        assert rc == 0 and r.frames == 512
+        assert r.global_peak == case["vu"]["global_peak"]
+        assert r.global_power == case["vu"]["global_power"]
+        pos += 512
+    b.close()
+
+
+def test_null_source_is_minus_inf(gpu, golden):
+    cm = gpu
+    b = cm.Batch(3, 2, 256, flags=cm.VU | cm.OUT_PCM)
+    b.generate(cm.GEN_NULL, 0, 256)
+    b.run(256)
+    res, rcs = b.vu_results()
+    for s in range(3):
+        assert rcs[s] == 0 and res[s].frames == 256 and res[s].global_peak == 0
+        assert res[s].global_power == -math.inf
+        assert res[s].channel_power[0] == -math.inf and res[s].channel_power[1] == -math.inf
+    b.close()
+
+
+def test_generators_match_host_generators(gpu, oracle):
+    cm = gpu
+    S, T = 5, 1000
+    for C in (1, 2, 3):
+        b = cm.Batch(S, C, T, flags=cm.VU)
+        b.generate(cm.GEN_NOISE, 12345, T, first_global=3, global_step=8, frame_offset=77)
+        for s in range(S):
+            gs = 3 + 8 * s
+            full = oracle.lcg(12345 + gs, (77 + T) * C)
+            assert np.array_equal(b.download_input(s, T), full[77 * C:]), (C, s)
+        b.generate(cm.GEN_SINE, 0, T, first_global=1, global_step=2, frame_offset=5)
+        rc, table = oracle.sine_table(48000)
+        for s in range(S):
+            gs = 1 + 2 * s
+            want = np.repeat(table[(np.arange(T) + 5 + 7 * gs) % 48], C)
+            assert np.array_equal(b.download_input(s, T), want), (C, s)
+        b.close()
+
+
+@pytest.mark.parametrize("C", [1, 2, 3, 4, 5, 6, 8, 11, 16])
+def test_random_blocks_bit_exact(gpu, oracle, C):
+    """ragged stream lengths, random gains/scales/maps, PCM + VU compared per stream"""
+    cm = gpu
+    rng = np.random.default_rng(1000 + C)
+    lens = [0, 1, 2, 3, 7, 8, 9, 63, 64, 65, 255, 511, 1000, 4095, 4096, 4097, 5000]
+    S = len(lens)
+    T = max(lens)
+    for inplace in (False, True):
+        flags = cm.OUT_PCM | cm.VU | (cm.INPLACE if inplace else 0)
+        b = cm.Batch(S, C, T, flags=flags)
+        params = []
+        for s in range(S):
+            kind = ["full", "edges", "small"][s % 3]
+            x = _rand_pcm(rng, lens[s] * C, kind)
+            mode = s % 5
+            if mode == 0:
+                ga = None                                          # never set: disabled
+            elif mode == 1:
+                ga = (C, int(rng.integers(1, 65536)), [int(v) for v in rng.integers(0, 65536, C)])
+            elif mode == 2:
+                ga = (1, int(rng.choice([1, 2, 1000, 32768, 65535])), [int(rng.integers(0, 65536))])
+            elif mode == 3:
+                ga = (C, 1, [65535] * C)
+            else:
+                ga = (C, 65535, [int(v) for v in rng.integers(0, 65536, C)])
+            cmap = None if s % 2 == 0 else [int(v) for v in rng.integers(0, C, C)]
+            if ga is not None:
+                assert b.set_gain(s, *ga) == 0
+            if cmap is not None:
+                assert b.set_chmap(s, cmap) == 0
+            if lens[s]:
+                b.upload(s, x)
+            params.append((x, ga, cmap))
+        b.run(T, frames_per_stream=lens)
+        for s in range(S):
+            x, ga, cmap = params[s]
+            want = _oracle_block(oracle, x, C, ga, cmap)
+            got = b.download(s, lens[s]) if lens[s] else np.zeros(0, np.int16)
+            assert np.array_equal(got, want), (C, s, inplace)
+            rc_o, r_o = _oracle_vu(oracle, [want], C)
+            rc_g, r_g = b.vu_result(s)
+            assert rc_g == rc_o, (C, s)
+            if rc_o == 0:
+                assert r_g.as_dict() == of.vu_result_dict(r_o), (C, s, inplace)
+        b.close()
+
+
+@pytest.mark.parametrize("C", [1, 2, 5])
+def test_vu_only_and_float_outputs(gpu, oracle, C):
+    cm = gpu
+    rng = np.random.default_rng(50 + C)
+    S, T = 6, 3001
+    gains = [int(v) for v in rng.integers(100, 3000, C)]
+    xs = [_rand_pcm(rng, T * C, "full") for _ in range(S)]
+    wants = [_oracle_block(oracle, x, C, (C, 1000, gains), None) for x in xs]
+    # VU only (no PCM is written anywhere)
+    b = cm.Batch(S, C, T, flags=cm.VU)
+    assert b.set_gain(-1, C, 1000, gains) == 0
+    for s in range(S):
+        b.upload(s, xs[s])
+    b.run(T)
+    for s in range(S):
+        rc, r = b.vu_result(s)
+        _, ro = _oracle_vu(oracle, [wants[s]], C)
+        assert rc == 0 and r.as_dict() == of.vu_result_dict(ro)
+    b.close()
+    # planar float = transformed PCM / 32768.f (ref: src/enc_vorbis.c:108-115), exact
+    for flags in (cm.OUT_F32, cm.OUT_F32 | cm.VU, cm.OUT_F32 | cm.OUT_PCM | cm.VU):
+        b = cm.Batch(S, C, T, flags=flags)
+        assert b.set_gain(-1, C, 1000, gains) == 0
+        for s in range(S):
+            b.upload(s, xs[s])
+        b.run(T)
+        for s in range(S):
+            planar = oracle.to_f32_planar(wants[s], C)
+            for c in range(C):
+                got = b.download_f32(s, c, T)
+                assert np.array_equal(got.view(np.uint32), planar[c].view(np.uint32)), (C, s, c)
+        b.close()
+
+
+def test_peak_tie_breaks_across_lanes_waves_chunks_and_launches(gpu, oracle):
+    """first max-|x| in interleaved order wins, also when the candidates sit in
+    different lanes, waves, wave-chunks or launches (ref: src/vumeter.c:163-168)"""
+    cm = gpu
+    T = 70000                      # several wave-chunks per stream
+    for C in (1, 2, 3):
+        spots = [(5, 3000), (9, -3000), (1023, 3000), (1024, -3000), (8 * 64 * 4 + 1, 3000),
+                 (40000, -3000), (69999, 3000)]
+        cases = []
+        for first in range(len(spots)):
+            x = np.zeros(T * C, dtype=np.int16)
+            for (f, v) in spots[first:]:
+                x[f * C + (C - 1)] = v
+            cases.append(x)
+        # equal magnitudes on different channels: global peak is the earliest sample
+        x = np.zeros(T * C, dtype=np.int16)
+        x[100 * C + 0] = -777
+        if C > 1:
+            x[50 * C + 1] = 777
+        cases.append(x)
+        S = len(cases)
+        b = cm.Batch(S, C, T, flags=cm.VU)
+        for s in range(S):
+            b.upload(s, cases[s])
+        b.run(T)
+        for s in range(S):
+            rc, r = b.vu_result(s)
+            _, ro = _oracle_vu(oracle, [cases[s]], C)
+            assert rc == 0 and r.as_dict() == of.vu_result_dict(ro), (C, s)
+        # same value in two launches of one window: the first launch keeps the peak
+        blk1 = np.zeros(T * C, dtype=np.int16)
+        blk2 = np.zeros(T * C, dtype=np.int16)
+        blk1[(T - 1) * C] = -1234
+        blk2[0] = 1234
+        for s in range(S):
+            b.upload(s, blk1)
+        b.run(T)
+        for s in range(S):
+            b.upload(s, blk2)
+        b.run(T)
+        rc, r = b.vu_result(0)
+        _, ro = _oracle_vu(oracle, [blk1, blk2], C)
+        assert rc == 0 and r.as_dict() == of.vu_result_dict(ro)
+        assert r.global_peak == -1234 and r.frames == 2 * T
+        b.close()
+
+
+def test_window_is_chunk_size_invariant(gpu, oracle):
+    """a VU window does not depend on how the stream is cut into launches"""
+    cm = gpu
+    C, T = 2, 8192
+    x = oracle.lcg(4242, T * C)
+    one = cm.Batch(1, C, T, flags=cm.VU)
+    one.upload(0, x)
+    one.run(T)
+    _, r1 = one.vu_result(0)
+    many = cm.Batch(1, C, 1000, flags=cm.VU)
+    pos = 0
+    for n in (1, 7, 1000, 999, 512, 3, 1000, 1000, 1000, 1000, 670):
+        many.upload(0, x[pos * C:(pos + n) * C])
+        many.run(n)
+        pos += n
+    assert pos == T
+    _, r2 = many.vu_result(0)
+    assert r1.as_dict() == r2.as_dict()
+    _, ro = _oracle_vu(oracle, [x], C)
+    assert r1.as_dict() == of.vu_result_dict(ro)
+    one.close()
+    many.close()
+
+
+def test_every_scale_divides_exactly_on_device(gpu, oracle):
+    """the mul-hi division against C's truncating division for awkward scales"""
+    cm = gpu
+    xs = np.array([-32768, -32767, -12345, -3, -2, -1, 0, 1, 2, 3, 12345, 32766, 32767], np.int16)
+    scales = [1, 2, 3, 5, 7, 10, 255, 256, 257, 641, 1000, 4095, 4096, 4097, 21845, 32767, 32768,
+              32769, 43691, 65521, 65534, 65535]
+    gains = [0, 1, 2, 3, 999, 1000, 1001, 32767, 32768, 65534, 65535]
+    S = len(scales) * len(gains)
+    b = cm.Batch(S, 1, 16, flags=cm.OUT_PCM)
+    combos = [(sc, g) for sc in scales for g in gains]
+    for s, (sc, g) in enumerate(combos):
+        assert b.set_gain(s, 1, sc, [g]) == 0
+        b.upload(s, xs)
+    b.run(xs.size)
+    for s, (sc, g) in enumerate(combos):
+        want = _oracle_block(oracle, xs, 1, (1, sc, [g]), None)
+        assert np.array_equal(b.download(s, xs.size), want), (sc, g)
+    b.close()
+
+
+def test_results_for_all_streams_and_snapshot_overlap(gpu, oracle):
+    cm = gpu
+    S, C, T = 37, 2, 2048
+    b = cm.Batch(S, C, T, flags=cm.VU | cm.OUT_PCM)
+    assert b.set_gain(-1, 2, 1000, [750, 1250]) == 0
+    assert b.set_chmap(-1, [1, 0]) == 0
+    b.generate(cm.GEN_NOISE, 999, T)
+    b.run(T)
+    b.vu_snapshot()                       # window 1 travels to the host ...
+    b.generate(cm.GEN_NOISE, 555, T)
+    b.run(T)                              # ... while window 2 accumulates
+    res1, rc1 = b.vu_collect()
+    res1 = [r.as_dict() for r in res1]
+    res2, rc2 = b.vu_results()
+    for s in range(S):
+        for seed, res, rcs in ((999, res1, rc1), (555, res2, rc2)):
+            want = _oracle_block(oracle, oracle.lcg(seed + s, T * C), C, (2, 1000, [750, 1250]),
+                                 [1, 0])
+            _, ro = _oracle_vu(oracle, [want], C)
+            got = res[s] if isinstance(res[s], dict) else res[s].as_dict()
+            assert rcs[s] == 0 and got == of.vu_result_dict(ro), (s, seed)
+    b.close()
+
+
+def test_node_partial_matches_host_merge(gpu, oracle):
+    """config 5's per-GPU record; two 'ranks' emulated as two batches on this GPU and
+    combined on the host the way the all-reduce combines them (SUM / MAX)"""
+    import torch
+    cm = gpu
+    C, T, S = 2, 4096, 16
+    N = 2
+    words = []
+    allblocks = []
+    for rank in range(N):
+        b = cm.Batch(S // N, C, T, flags=cm.VU)
+        assert b.set_gain(-1, 2, 1000, [750, 1250]) == 0
+        b.generate(cm.GEN_NOISE, 31337, T, first_global=rank, global_step=N)
+        b.run(T)
+        dst = torch.zeros(cm.NODE_WORDS, dtype=torch.int64, device="cuda:0")
+        b.node_partial(dst.data_ptr(), first_global=rank, global_step=N)
+        b.sync()
+        words.append(dst.cpu().numpy())
+        for s in range(S // N):
+            gs = rank + N * s
+            allblocks.append(_oracle_block(oracle, oracle.lcg(31337 + gs, T * C), C,
+                                           (2, 1000, [750, 1250]), None))
+        b.close()
+    merged = np.concatenate([words[0][:17] + words[1][:17],
+                             np.maximum(words[0][17:], words[1][17:])])
+    rc, r = cm.node_finish(merged, C)
+    assert rc == 0 and r.frames == S * T
+    # expected: sums over all streams; peak = largest magnitude over all streams
+    pw = np.zeros(C, dtype=np.int64)
+    peaks = []
+    for blk in allblocks:
+        v = oracle.vu_new(C)
+        oracle.vu_accumulate(v, blk)
+        pw += np.array([v.power[c] for c in range(C)], dtype=np.int64)
+        peaks.append([v.result.channel_peak[c] for c in range(C)])
+    for c in range(C):
+        assert r.channel_power[c] == oracle.lib.oracle_power_db(int(pw[c]), S * T)
+        assert abs(int(r.channel_peak[c])) == max(abs(int(p[c])) for p in peaks)
+    assert r.global_power == oracle.lib.oracle_power_db(int(pw.sum()), S * T * C)
+    assert abs(int(r.global_peak)) == max(abs(int(v)) for p in peaks for v in p)
+
+
+def test_full_size_config2_properties(gpu, oracle):
+    """BASELINE config 2 at full size (4096 x 2ch x 65536 frames): sampled streams against
+    the oracle, VU-only run equal to the PCM run, two half-blocks equal to one block."""
+    cm = gpu
+    S, C, T = 4096, 2, 65536
+    gains, cmap = [750, 1250], [1, 0]
+    b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU)
+    assert b.set_gain(-1, 2, 1000, gains) == 0 and b.set_chmap(-1, cmap) == 0
+    b.generate(cm.GEN_NOISE, 12345, T)
+    b.run(T)
+    res, rcs = b.vu_results()
+    full = [r.as_dict() for r in res]
+    assert all(rc == 0 for rc in rcs)
+    for s in (0, 1, 7, 2047, 4095):
+        want = _oracle_block(oracle, oracle.lcg(12345 + s, T * C), C, (2, 1000, gains), cmap)
+        assert np.array_equal(b.download(s, T), want), s
+        _, ro = _oracle_vu(oracle, [want], C)
+        assert full[s] == of.vu_result_dict(ro), s
+    # checksum of checksums: total power over all streams equals the sum of per-stream raws
+    b.close()
+    v = cm.Batch(S, C, T // 2, flags=cm.VU)
+    assert v.set_gain(-1, 2, 1000, gains) == 0 and v.set_chmap(-1, cmap) == 0
+    for half in range(2):
+        v.generate(cm.GEN_NOISE, 12345, T // 2, frame_offset=half * (T // 2))
+        v.run(T // 2)
+    res2, rcs2 = v.vu_results()
+    assert all(rc == 0 for rc in rcs2)
+    bad = [s for s in range(S) if res2[s].as_dict() != full[s]]
+    assert not bad, bad[:8]
+    v.close()

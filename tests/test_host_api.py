@@ -1,0 +1,258 @@
+"""CPU: host logic of the drop-in boundary -- handles, refcounts, sources, framing,
+parameter rules, division constants -- everything that needs no arithmetic on PCM.
+The arithmetic itself only exists on the GPU (tests/test_gpu_*.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def test_iohandle_contract(cm):
+    # ref: src/iohandle.c:54-113
+    assert not cm.lib.coolmic_iohandle_new(None, None, None, cm.FREE_FN(), cm.READ_FN(), cm.EOF_FN())
+    buf = (C.c_ubyte * 8)()
+    assert cm.lib.coolmic_iohandle_read(None, buf, 8) == cm.ERROR_FAULT
+    assert cm.lib.coolmic_iohandle_eof(None) == cm.ERROR_FAULT
+
+    script = [b"ab", b"cde", 0, b"zz"]
+    h = cm.IoHandle.from_callbacks(lambda n: script.pop(0))
+    assert cm.lib.coolmic_iohandle_read(h.ptr, None, 8) == cm.ERROR_FAULT
+    assert cm.lib.coolmic_iohandle_read(h.ptr, buf, 0) == 0
+    n, data = h.read(8)                  # loops until a 0 comes back
+    assert (n, data) == (5, b"abcde")
+    assert h.eof() == 0                  # no eof callback: endless
+    h.unref()
+
+    script = [b"xy", -1]
+    h = cm.IoHandle.from_callbacks(lambda n: script.pop(0))
+    assert h.read(8) == (2, b"xy")       # error after data: the data
+    script[:] = [-1]
+    assert h.read(8)[0] == -1            # error with nothing: the error
+    script[:] = [-9]
+    assert h.read(8)[0] == -9
+    h.unref()
+
+    h = cm.IoHandle.from_bytes(b"0123456789", chunk=3)
+    assert h.read(4) == (4, b"0123") and h.eof() == 0
+    assert h.read(100) == (6, b"456789") and h.eof() == 1
+    h.unref()
+
+
+def test_refcounting_and_ownership(cm):
+    # ref: src/transform.c:83-99,181-193 and the attach-then-unref idiom of src/simple.c:212-229
+    freed = []
+    src = cm.IoHandle.from_callbacks(lambda n: 0, free=lambda: freed.append("src"))
+    assert src.refcount() == 1
+    tr = cm.Transform(48000, 2)
+    assert tr.attach(src) == 0 and src.refcount() == 2
+    src_ptr = src.ptr
+    src.unref()                                   # the transform now holds the only reference
+    assert cm.lib.coolmic_ro_refcount(src_ptr) == 1 and not freed
+    h = tr.get_iohandle()
+    assert tr.refcount() == 2                     # the handle keeps its transform alive
+    tr_ptr = tr.ptr
+    tr.unref()
+    assert cm.lib.coolmic_ro_refcount(tr_ptr) == 1
+    h.unref()                                     # last handle -> transform -> source
+    assert freed == ["src"]
+    # NULL is a reported, harmless error
+    assert cm.lib.coolmic_ro_ref(None) == cm.ERROR_FAULT
+    assert cm.lib.coolmic_ro_unref(None) == cm.ERROR_FAULT
+    # re-attaching replaces and releases the previous handle; NULL detaches
+    a = cm.IoHandle.from_callbacks(lambda n: 0, free=lambda: freed.append("a"))
+    b = cm.IoHandle.from_callbacks(lambda n: 0, free=lambda: freed.append("b"))
+    vu = cm.Vumeter(48000, 1)
+    assert vu.attach(a) == 0 and vu.attach(b) == 0
+    a.unref()
+    assert freed == ["src", "a"]
+    assert vu.attach(None) == 0
+    b.unref()
+    assert freed == ["src", "a", "b"]
+    vu.unref()
+    assert cm.lib.coolmic_transform_attach_iohandle(None, None) == cm.ERROR_FAULT
+    assert cm.lib.coolmic_vumeter_attach_iohandle(None, None) == cm.ERROR_FAULT
+
+
+def test_constructors_reject_bad_formats(cm):
+    for rate, ch in ((0, 1), (48000, 0), (48000, 17)):
+        assert not cm.lib.coolmic_transform_new(None, None, rate, ch)
+        assert not cm.lib.coolmic_vumeter_new(None, None, rate, ch)
+    # ref: src/snddev.c:104-129, src/snddev_sine.c:172-177
+    new = cm.lib.coolmic_snddev_new
+    assert not new(None, None, b"sine", None, 48000, 2, 1, -1)      # sine is mono only
+    assert not new(None, None, b"sine", None, 22050, 1, 1, -1)      # rate without a table
+    assert not new(None, None, b"alsa", None, 48000, 1, 1, -1)      # unknown driver
+    assert not new(None, None, b"null", None, 48000, 1, 0, -1)      # no flags
+    d = new(None, None, b"SINE", None, 48000, 1, 1, -1)             # case-insensitive
+    assert d
+    cm.lib.coolmic_ro_unref(d)
+    d = new(None, None, None, None, 48000, 2, 1, -1)                # AUTO
+    assert d
+    cm.lib.coolmic_ro_unref(d)
+
+
+def test_sources_match_oracle_sources(cm, oracle):
+    from oracle import oracle_ffi as of
+    for rate in (8000, 16000, 24000, 32000, 44000, 44100, 48000, 96000):
+        rc, t = cm.sine_period(rate)
+        rco, to = oracle.sine_table(rate)
+        assert rc == rco == 0 and np.array_equal(t, to)
+    assert cm.sine_period(11025)[0] == cm.ERROR_NOSYS
+    # byte-granular phase across odd-sized reads (ref: src/snddev_sine.c:118-150)
+    dev = cm.Snddev("sine", 48000, 1)
+    h = dev.get_iohandle()
+    sine = of.Sine()
+    oracle.lib.oracle_sine_init(C.byref(sine), 48000)
+    for n in (1, 3, 95, 96, 97, 1024, 5, 200):
+        got = h.read(n)
+        buf = (C.c_ubyte * n)()
+        assert oracle.lib.oracle_sine_read(C.byref(sine), buf, n) == n
+        assert got == (n, bytes(buf))
+    assert h.eof() == 0
+    h.unref(); dev.unref()
+    dev = cm.Snddev("null", 48000, 2)
+    h = dev.get_iohandle()
+    assert h.read(33) == (33, bytes(33))
+    h.unref(); dev.unref()
+
+
+def test_transform_framing_without_arithmetic(cm, golden):
+    """gain disabled is the reference's own early-out (ref: src/transform.c:107-108): the
+    framing logic can be exercised on the CPU box.  K7, K8, K9 shapes."""
+    x = np.array(golden["k_input_stereo"], dtype=np.int16).tobytes()
+    tr = cm.Transform(48000, 2)
+    tr.attach(cm.IoHandle.from_bytes(x))
+    h = tr.get_iohandle()
+    assert h.read(3) == (0, b"")                    # less than a frame asked: nothing
+    n, data = h.read(7)                             # K7: cut to one frame
+    assert (n, data) == (4, x[:4]) and h.eof() == 0
+    assert h.read(1000) == (12, x[4:]) and h.eof() == 1
+    h.unref()
+    # K8: upstream in 3-byte pieces, partial frames carried between reads
+    tr = cm.Transform(48000, 2)
+    tr.attach(cm.IoHandle.from_bytes(x, chunk=3))
+    h = tr.get_iohandle()
+    assert h.read(16) == (16, x)
+    h.unref()
+    # a short upstream read that ends inside a frame: the tail waits in the carry buffer
+    script = [x[:6], 0, 0, x[6:16], 0]   # the consumer-side loop asks again after a short read
+    tr = cm.Transform(48000, 2)
+    tr.attach(cm.IoHandle.from_callbacks(lambda n: script.pop(0) if script else 0))
+    h = tr.get_iohandle()
+    assert h.read(16) == (4, x[:4])
+    assert h.read(16) == (12, x[4:16])
+    h.unref()
+    # no upstream at all: FAULT from the handle is swallowed into an empty read, eof is 1
+    tr = cm.Transform(48000, 2)
+    h = tr.get_iohandle()
+    assert h.read(16) == (0, b"") and h.eof() == 1
+    h.unref(); tr.unref()
+    # K9: mono, scale 0 -> PCM unchanged
+    m = np.array(golden["k_input_mono"], dtype=np.int16).tobytes()
+    tr = cm.Transform(48000, 1)
+    tr.attach(cm.IoHandle.from_bytes(m))
+    assert tr.set_master_gain(1, 0, [123]) == 0
+    h = tr.get_iohandle()
+    assert h.read(len(m)) == (len(m), m)
+    h.unref()
+
+
+def test_set_master_gain_rules(cm):
+    # ref: src/transform.c:195-222
+    assert cm.lib.coolmic_transform_set_master_gain(None, 1, 1, None) == cm.ERROR_FAULT
+    st = cm.Transform(48000, 2)
+    assert st.set_master_gain(2, 1000, [750, 1250]) == 0
+    assert st.set_master_gain(1, 1000, [900]) == 0           # broadcast
+    assert st.set_master_gain(3, 1000, [1, 2, 3]) == cm.ERROR_INVAL
+    assert st.set_master_gain(0, 1000, [1]) == 0             # disable
+    assert st.set_master_gain(2, 0, [1, 1]) == 0             # disable
+    assert st.set_master_gain(2, 1000, None) == 0            # disable
+    mono = cm.Transform(48000, 1)
+    assert mono.set_master_gain(2, 1, [3, 4]) == 0           # stereo pair on mono: mean
+    assert mono.set_master_gain(3, 1, [3, 4, 5]) == cm.ERROR_INVAL
+    assert st.set_channel_map([1, 0]) == 0
+    assert st.set_channel_map([0, 2]) == cm.ERROR_INVAL
+    assert st.set_channel_map(None) == 0
+    st.unref(); mono.unref()
+
+
+def test_vumeter_host_rules(cm):
+    # ref: src/vumeter.c:148-151,195-199
+    assert cm.lib.coolmic_vumeter_read(None, -1) == -1
+    assert cm.lib.coolmic_vumeter_reset(None) == cm.ERROR_FAULT
+    vu = cm.Vumeter(48000, 2)
+    r = cm.VuResult()
+    assert cm.lib.coolmic_vumeter_result(None, C.byref(r)) == cm.ERROR_FAULT
+    assert cm.lib.coolmic_vumeter_result(vu.ptr, None) == cm.ERROR_FAULT
+    assert vu.result()[0] == cm.ERROR_INVAL                  # no frames yet
+    assert vu.reset() == 0
+    # upstream error with nothing buffered surfaces as -1; nothing to read gives 0
+    script = [-1, 0]
+    h = cm.IoHandle.from_callbacks(lambda n: script.pop(0))
+    vu.attach(h)
+    assert vu.read(-1) == -1
+    assert vu.read(-1) == 0
+    # a partial frame is only buffered (no arithmetic yet): 3 bytes of a 4-byte frame
+    script[:] = [b"abc", 0, -1]
+    assert vu.read(-1) == 3
+    assert vu.read(-1) == 0                                  # error hidden while bytes are buffered
+    assert vu.result()[0] == cm.ERROR_INVAL
+    h.unref(); vu.unref()
+
+
+def test_product_fails_loudly_without_gpu(cm):
+    if cm.device_count() > 0:
+        pytest.skip("a GPU is present")
+    logs = []
+    cm.set_log_callback(lambda lvl, msg: logs.append((lvl, msg)))
+    try:
+        with pytest.raises(cm.CoolmicError):
+            cm.Batch(1, 1, 64)
+        assert "no CPU path" in cm.last_error()
+        # a read that needs arithmetic cannot be served: -1 and an ERROR line, no CPU result
+        tr = cm.Transform(48000, 1)
+        tr.attach(cm.IoHandle.from_bytes(bytes(64)))
+        tr.set_master_gain(1, 2, [1])
+        h = tr.get_iohandle()
+        assert h.read(64)[0] == -1
+        vu = cm.Vumeter(48000, 1)
+        vu.attach(cm.IoHandle.from_bytes(bytes(64)))
+        assert vu.read(-1) == -1
+        assert any(lvl == 1 and "no CPU path" in msg for lvl, msg in logs)
+        assert all(msg.startswith("libcoolmic-dsp/") for _, msg in logs)
+        h.unref(); tr.unref(); vu.unref()
+    finally:
+        cm.set_log_callback(None)
+
+
+def test_division_constants_are_exact(cm):
+    """q = mulhi(2n, magic) >> shift equals n // scale for all scales and adversarial n
+    (n = |x|*gain < 2^31).  The GPU test repeats a subset on the device."""
+    rng = np.random.default_rng(3)
+    nmax = 32768 * 65535
+    for scale in list(range(1, 2050)) + [4095, 4096, 4097, 21845, 32767, 32768, 32769, 43691,
+                                          65521, 65534, 65535] + [int(v) for v in rng.integers(1, 65536, 300)]:
+        m, sh = cm.magic(scale)
+        assert m < 2 ** 32 and sh <= 16
+        ks = np.arange(0, nmax // scale + 2, max(1, (nmax // scale) // 257), dtype=np.uint64)
+        n = np.concatenate([ks * np.uint64(scale), ks * np.uint64(scale) + np.uint64(scale - 1),
+                            rng.integers(0, nmax + 1, 2000).astype(np.uint64),
+                            np.array([0, 1, nmax, nmax - 1], dtype=np.uint64)])
+        n = n[n <= nmax]
+        q = ((n * np.uint64(2) * np.uint64(m)) >> np.uint64(32)) >> np.uint64(sh)
+        assert np.array_equal(q, n // np.uint64(scale)), scale
+
+
+def test_logging_format(cm):
+    logs = []
+    cm.set_log_callback(lambda lvl, msg: logs.append((lvl, msg)))
+    try:
+        mono = cm.Transform(48000, 1)
+        mono.set_master_gain(2, 7, [3, 4])                  # logs at DEBUG (ref: src/transform.c:217)
+        mono.unref()
+    finally:
+        cm.set_log_callback(None)
+    assert logs and logs[0][0] == 4
+    assert "libcoolmic-dsp/transform in " in logs[0][1] and "DEBUG: gain: scale=7, gain[0]=3 (in: 3, 4)" in logs[0][1]
+    assert cm.lib.coolmic_logging_level2string(1) == b"ERROR"
+    assert cm.lib.coolmic_logging_level2string(99) == b"(unknown)"
