@@ -98,10 +98,11 @@ struct cmhip_batch {
     unsigned int stage_next;
     hipEvent_t snap_event;
     bool snap_pending;
+    unsigned int parity;                   // current slot of VuState::samples
+    unsigned int snap_parity;
 
     bool timing;
     std::vector<EventPair> ev_used, ev_free;
-    unsigned int iters_override;
 };
 
 static inline int use(cmhip_batch_t *b)
@@ -243,8 +244,6 @@ static int batch_init(cmhip_batch_t *b)
             b->h_param[s].chmap[c] = (uint8_t)(c < d.channels ? c : 0);
         rebuild_param(b, (unsigned)s);
     }
-    const char *it = getenv("CMHIP_ITERS");
-    b->iters_override = it ? (unsigned)atoi(it) : 0;
     HIP_TRY(hipStreamSynchronize(b->stream));
     return COOLMIC_ERROR_NONE;
 }
@@ -298,11 +297,12 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->stage_next = 0;
     b->snap_event = nullptr;
     b->snap_pending = false;
+    b->parity = 0;
+    b->snap_parity = 0;
     b->param_dirty = true;
     b->eq_dirty = false;
     b->nsec = 0;
     b->timing = false;
-    b->iters_override = 0;
     if (batch_init(b) != COOLMIC_ERROR_NONE) {
         cmhip_batch_free(b);
         return nullptr;
@@ -605,25 +605,12 @@ static int flush_params(cmhip_batch_t *b)
     return COOLMIC_ERROR_NONE;
 }
 
-static void pick_chunks(const cmhip_batch_t *b, size_t frames, uint32_t *vec_per_chunk,
-                        uint32_t *chunks)
+// one wave per 4 KiB tile: 256 vectors of 16 bytes
+static uint32_t tiles_per_stream(const cmhip_batch_t *b, size_t frames)
 {
-    // a wave walks 64*iters vectors; want >= 16 waves per SIMD over the chip
     const uint64_t nvec = ((uint64_t)frames * b->d.channels + 7) / 8;
-    const uint64_t want = 256ull * 4 * 16;
-    unsigned iters = 32;
-    if (b->iters_override) {
-        iters = (b->iters_override + 3) / 4 * 4;
-    } else {
-        while (iters > 4 && (uint64_t)b->d.streams * ((nvec + 64ull * iters - 1) / (64ull * iters)) < want)
-            iters -= 4;
-    }
-    if (iters > 1024)
-        iters = 1024;
-    *vec_per_chunk = 64u * iters;
-    *chunks = (uint32_t)((nvec + *vec_per_chunk - 1) / *vec_per_chunk);
-    if (*chunks == 0)
-        *chunks = 1;
+    const uint64_t t = (nvec + 255) / 256;
+    return (uint32_t)(t ? t : 1);
 }
 
 static EventPair take_events(cmhip_batch_t *b)
@@ -680,6 +667,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.frames = (uint32_t)frames;
         a.streams = b->d.streams;
         a.nsec = b->nsec;
+        a.parity = b->parity;
         a.stride = b->stride;
         a.plane = b->plane;
         HIP_TRY(launch_eq(a, b->stream));
@@ -697,7 +685,10 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.channels = b->d.channels;
         a.stride = b->stride;
         a.plane = b->plane;
-        pick_chunks(b, frames, &a.vec_per_chunk, &a.chunks);
+        a.chunks = tiles_per_stream(b, frames);
+        a.parity = b->parity;
+        if ((uint64_t)a.chunks * a.streams >= (1ull << 31))
+            return fail(COOLMIC_ERROR_INVAL, "run: too many tiles for one launch");
         HIP_TRY(launch_run(a, b->stream));
     }
     if (b->timing) {
@@ -705,8 +696,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         b->ev_used.push_back(ev);
     }
     if (vu)
-        HIP_TRY(launch_vu_advance(b->d_vu, frames_per_stream ? b->d_nframes : nullptr,
-                                  (uint32_t)frames, b->d.streams, b->d.channels, b->stream));
+        b->parity ^= 1u;                   // the kernel wrote the other samples slot
     return COOLMIC_ERROR_NONE;
 }
 
@@ -737,10 +727,11 @@ static double power_db(unsigned long long sum, unsigned long long count)
     return fmin(p, 0.);
 }
 
-static int finish_window(const cmhip_batch_t *b, const VuState &v, coolmic_vumeter_result_t *out)
+static int finish_window(const cmhip_batch_t *b, const VuState &v, unsigned parity,
+                         coolmic_vumeter_result_t *out)
 {
     const unsigned C = b->d.channels;
-    const unsigned long long frames = v.samples / C;
+    const unsigned long long frames = v.samples[parity] / C;
     if (frames == 0)
         return COOLMIC_ERROR_INVAL;                      // ref: src/vumeter.c:198-199
     memset(out, 0, sizeof(*out));
@@ -772,7 +763,7 @@ extern "C" int cmhip_batch_vu_result(cmhip_batch_t *b, unsigned int stream,
     VuState v;
     HIP_TRY(hipMemcpyAsync(&v, b->d_vu + stream, sizeof(v), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
-    const int rc = finish_window(b, v, out);
+    const int rc = finish_window(b, v, b->parity, out);
     if (rc == COOLMIC_ERROR_NONE)
         HIP_TRY(hipMemsetAsync(b->d_vu + stream, 0, sizeof(VuState), b->stream));
     return rc;
@@ -792,6 +783,7 @@ extern "C" int cmhip_batch_vu_snapshot(cmhip_batch_t *b)
     HIP_TRY(hipMemcpyAsync(b->h_snap, b->d_vu, bytes, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipMemsetAsync(b->d_vu, 0, bytes, b->stream));
     HIP_TRY(hipEventRecord(b->snap_event, b->stream));
+    b->snap_parity = b->parity;
     b->snap_pending = true;
     return COOLMIC_ERROR_NONE;
 }
@@ -807,7 +799,7 @@ extern "C" int cmhip_batch_vu_collect(cmhip_batch_t *b, coolmic_vumeter_result_t
     HIP_TRY(hipEventSynchronize(b->snap_event));
     b->snap_pending = false;
     for (unsigned s = 0; s < b->d.streams; s++) {
-        const int r = finish_window(b, b->h_snap[s], &out[s]);
+        const int r = finish_window(b, b->h_snap[s], b->snap_parity, &out[s]);
         if (rc)
             rc[s] = r;
     }
@@ -857,7 +849,7 @@ extern "C" int cmhip_batch_vu_raw(cmhip_batch_t *b, unsigned int stream, int64_t
             peak[c] = key_peak(v.key[c]);
     }
     if (frames)
-        *frames = v.samples / b->d.channels;
+        *frames = v.samples[b->parity] / b->d.channels;
     return COOLMIC_ERROR_NONE;
 }
 
@@ -873,7 +865,7 @@ extern "C" int cmhip_batch_vu_node_partial(cmhip_batch_t *b, void *dst_device,
         return fail(COOLMIC_ERROR_INVAL, "vu_node_partial: batch without VU");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
-    HIP_TRY(launch_node_partial(b->d_vu, b->d.streams, b->d.channels, first_global, global_step,
+    HIP_TRY(launch_node_partial(b->d_vu, b->d.streams, b->d.channels, b->parity, first_global, global_step,
                                 (long long *)dst_device, b->stream));
     return COOLMIC_ERROR_NONE;
 }

@@ -35,7 +35,10 @@ struct StreamParam {
 struct VuState {
     unsigned long long power[MAX_CH];
     unsigned long long key[MAX_CH];
-    unsigned long long samples;          // interleaved samples accounted so far
+    // interleaved samples accounted so far.  Two slots: a run reads slot `parity` and the
+    // stream's first tile writes slot `parity^1`, so no wave can see a half-updated value
+    // and no extra kernel is needed to advance the window; the host flips parity per run.
+    unsigned long long samples[2];
 };
 
 constexpr int      KEY_ABS_SHIFT = 47;
@@ -61,8 +64,8 @@ struct RunArgs {
     uint32_t       channels;
     uint64_t       stride;         // samples between stream slots (multiple of 8)
     uint64_t       plane;          // floats between planes of the f32 output
-    uint32_t       vec_per_chunk;  // 16-byte vectors one wave walks (multiple of 256)
-    uint32_t       chunks;         // wave-chunks per stream
+    uint32_t       chunks;         // 4 KiB tiles (one wave each) per stream slot
+    uint32_t       parity;         // which VuState::samples slot is current
 };
 
 struct EqArgs {
@@ -77,6 +80,7 @@ struct EqArgs {
     uint32_t       frames;
     uint32_t       streams;
     uint32_t       nsec;           // biquad sections, same for every stream of the batch
+    uint32_t       parity;
     uint64_t       stride;
     uint64_t       plane;
 };
@@ -92,13 +96,11 @@ struct GenArgs {
 
 // launchers (cmhip_kernels.hip)
 hipError_t launch_run(const RunArgs &a, hipStream_t st);
-hipError_t launch_vu_advance(VuState *vu, const uint32_t *nframes, uint32_t frames,
-                             uint32_t streams, uint32_t channels, hipStream_t st);
 hipError_t launch_eq(const EqArgs &a, hipStream_t st);
 hipError_t launch_generate(const GenArgs &a, int mode, hipStream_t st);
 hipError_t launch_node_partial(const VuState *vu, uint32_t streams, uint32_t channels,
-                               uint64_t first_global, uint64_t global_step, long long *dst,
-                               hipStream_t st);
+                               uint32_t parity, uint64_t first_global, uint64_t global_step,
+                               long long *dst, hipStream_t st);
 hipError_t launch_ceiling(int mode, const void *src, void *dst, size_t bytes,
                           unsigned long long *sink, hipStream_t st);
 

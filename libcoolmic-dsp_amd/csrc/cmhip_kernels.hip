@@ -21,7 +21,6 @@ namespace cmhip {
 using u32 = uint32_t;
 using u64 = unsigned long long;
 
-constexpr u32 ORD_MAX = 32767;      // per-lane sample ordinals fit 15 bits
 
 __device__ __forceinline__ u32 uniform(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -62,215 +61,317 @@ __device__ __forceinline__ u64 make_key(u32 mag, u64 index, u32 neg)
 
 // ---------------------------------------------------------------------------
 // Fast path: mono and stereo, any stereo channel map, slots 16-byte aligned.
+//
+// Every integer VALU op costs about the same on gfx950 (tools/ubench_valu.hip: mul_hi,
+// mul_lo, 24-bit multiplies, packed-16 ops and three-operand ops all issue in ~4 cycles
+// per wave, only two-operand 32-bit adds and fp32 multiplies are quicker), so the kernel
+// is built to minimise the instruction count per sample: the two int16 halves of a dword
+// are handled by packed-16 instructions wherever no 32-bit intermediate is needed
+// (sign masks, magnitudes, saturation, sign restore, running maximum), and only the
+// exact division (24-bit multiply, mul_hi, shift) is done per sample.
+//
+// Peak tracking costs ~1 op per sample: per 16-byte vector a packed running maximum of
+// the magnitudes is folded into a per-lane key (magnitude, vector ordinal); which sample
+// of the winning vector came first, and its sign, is found once per wave by looking at
+// that one vector again (locate_peak).
 
-template <int C, bool DO_VU>
-struct LaneAcc {
-    u64 pow[C];
-    u32 best[C];
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32 pk_sign(u32 w)          // 0xffff in each negative half
+{
+    v2s v = __builtin_bit_cast(v2s, w);
+    v = v >> (short)15;
+    return __builtin_bit_cast(u32, v);
+}
+__device__ __forceinline__ u32 pk_sub(u32 a, u32 b)
+{
+    v2u x = __builtin_bit_cast(v2u, a) - __builtin_bit_cast(v2u, b);
+    return __builtin_bit_cast(u32, x);
+}
+__device__ __forceinline__ u32 pk_min(u32 a, u32 b)
+{
+    v2u x = __builtin_elementwise_min(__builtin_bit_cast(v2u, a), __builtin_bit_cast(v2u, b));
+    return __builtin_bit_cast(u32, x);
+}
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b)
+{
+    v2u x = __builtin_elementwise_max(__builtin_bit_cast(v2u, a), __builtin_bit_cast(v2u, b));
+    return __builtin_bit_cast(u32, x);
+}
+
+// one dword = two samples: returns the packed magnitudes after gain + saturation,
+// `out` receives the packed signed result
+__device__ __forceinline__ u32 gain2(u32 w, u32 g2lo, u32 g2hi, u32 magic, u32 shift, u32 &out)
+{
+    const u32 sg = pk_sign(w);
+    const u32 aw = pk_sub(w ^ sg, sg);                       // |x| per half (u16, 32768 ok)
+    const u32 n0 = __umul24(aw & 0xffffu, g2lo);             // 2*|x|*gain < 2^32
+    const u32 n1 = __umul24(aw >> 16, g2hi);
+    const u32 q0 = __umulhi(n0, magic) >> shift;             // floor(|x|*gain/scale)
+    const u32 q1 = __umulhi(n1, magic) >> shift;
+    u32 qw = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pk_u16(q0, q1));   // saturates at 65535
+    qw = pk_min(qw, pk_sub(0x7fff7fffu, sg));                // 32767, or 32768 for negatives
+    out = pk_sub(qw ^ sg, sg);
+    return qw;
+}
+
+// sum of squares with as few 64-bit additions as exactness allows: three squares
+// (each <= 2^30) fit a u32
+struct PowAcc {
+    u64 total;
+    u32 part;
+    u32 n;
+    __device__ __forceinline__ void add(u32 mag)
+    {
+        part += mag * mag;
+        if (++n == 3)
+            flush();
+    }
+    __device__ __forceinline__ void flush()
+    {
+        total += part;
+        part = 0;
+        n = 0;
+    }
 };
 
-// eight consecutive samples of one lane: gain, saturate, account
-template <int C, bool DO_VU>
-__device__ __forceinline__ void core8(const int (&x)[8], int (&q)[8], const u32 (&g2)[C],
-                                      u32 magic, u32 shift, u32 tagbase, LaneAcc<C, DO_VU> &acc)
-{
-    u32 m[8];
-    int sg[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        m[j] = gain_mag(x[j], g2[j % C], magic, shift, sg[j]);
-        q[j] = (int)((m[j] ^ (u32)sg[j]) - (u32)sg[j]);
-    }
-    if constexpr (DO_VU) {
-        u32 sq[8], key[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            sq[j] = __umul24(m[j], m[j]);                                // <= 2^30
-            // |q| above, then (ORD_MAX - ordinal) and the sign bit: larger = bigger
-            // magnitude, then earlier sample
-            key[j] = ((m[j] << 16) + (tagbase - 2u * (u32)j)) - (u32)sg[j];
-        }
-        if constexpr (C == 1) {
-            acc.pow[0] += (u64)(sq[0] + sq[1] + sq[2]);                  // 3*2^30 < 2^32
-            acc.pow[0] += (u64)(sq[3] + sq[4] + sq[5]);
-            acc.pow[0] += (u64)(sq[6] + sq[7]);
-            u32 b = acc.best[0];
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                b = key[j] > b ? key[j] : b;
-            acc.best[0] = b;
-        } else {
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                acc.pow[c] += (u64)(sq[c] + sq[c + 2] + sq[c + 4]);
-                acc.pow[c] += (u64)sq[c + 6];
-                u32 b = acc.best[c];
-#pragma unroll
-                for (int j = c; j < 8; j += 2)
-                    b = key[j] > b ? key[j] : b;
-                acc.best[c] = b;
-            }
-        }
-    }
-}
-
 template <int C>
-__device__ __forceinline__ void unpack8(const uint4 &w, u32 perm2, int (&x)[8])
-{
-    u32 d[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        u32 v = d[i];
-        if constexpr (C == 2)
-            v = __builtin_amdgcn_perm(v, v, perm2);      // stereo channel map
-        x[2 * i] = (int)(short)(v & 0xffffu);
-        x[2 * i + 1] = (int)v >> 16;
-    }
-}
-
-__device__ __forceinline__ uint4 pack8(const int (&q)[8])
-{
-    uint4 r;
-    r.x = ((u32)q[0] & 0xffffu) | ((u32)q[1] << 16);
-    r.y = ((u32)q[2] & 0xffffu) | ((u32)q[3] << 16);
-    r.z = ((u32)q[4] & 0xffffu) | ((u32)q[5] << 16);
-    r.w = ((u32)q[6] & 0xffffu) | ((u32)q[7] << 16);
-    return r;
-}
-
-template <int C>
-__device__ __forceinline__ void store_f32(float *f32s, u64 plane, u32 v, const int (&q)[8])
+__device__ __forceinline__ void store_f32(float *f32s, u64 plane, u32 v, const u32 (&o)[4])
 {
     constexpr float k = 1.0f / 32768.0f;                 // exact scaling == x / 32768.f
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        f[2 * i] = (float)(int)(short)(o[i] & 0xffffu) * k;
+        f[2 * i + 1] = (float)((int)o[i] >> 16) * k;
+    }
     if constexpr (C == 1) {
-        float4 a = {q[0] * k, q[1] * k, q[2] * k, q[3] * k};
-        float4 b = {q[4] * k, q[5] * k, q[6] * k, q[7] * k};
         float4 *p = reinterpret_cast<float4 *>(f32s + (u64)v * 8);
-        p[0] = a;
-        p[1] = b;
+        p[0] = make_float4(f[0], f[1], f[2], f[3]);
+        p[1] = make_float4(f[4], f[5], f[6], f[7]);
     } else {
-        float4 l = {q[0] * k, q[2] * k, q[4] * k, q[6] * k};
-        float4 r = {q[1] * k, q[3] * k, q[5] * k, q[7] * k};
-        *reinterpret_cast<float4 *>(f32s + (u64)v * 4) = l;
-        *reinterpret_cast<float4 *>(f32s + plane + (u64)v * 4) = r;
+        *reinterpret_cast<float4 *>(f32s + (u64)v * 4) = make_float4(f[0], f[2], f[4], f[6]);
+        *reinterpret_cast<float4 *>(f32s + plane + (u64)v * 4) = make_float4(f[1], f[3], f[5], f[7]);
     }
 }
 
-template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU>
-__global__ __launch_bounds__(256) void k_run_fast(RunArgs a)
+// scalar form of the same arithmetic, used for the samples of a ragged tail
+__device__ __forceinline__ int gain1(int x, u32 g2, u32 magic, u32 shift, u32 &mag)
 {
-    const u32 lane = threadIdx.x & 63u;
-    const u32 gw = uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
-    const u32 s = gw / a.chunks;                 // stream, wave-uniform
-    const u32 k = gw - s * a.chunks;             // chunk inside the stream
-    if (s >= a.streams)
-        return;
+    int sg;
+    mag = gain_mag(x, g2, magic, shift, sg);
+    return (int)((mag ^ (u32)sg) - (u32)sg);
+}
+
+// wave64 reductions on the VALU (DPP), result valid in lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp0(u32 v)       // lanes without a source read 0
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ u32 wave_max_u32(u32 v)
+{
+    v = max(v, dpp0<0x111, 0xf>(v));             // row_shr:1
+    v = max(v, dpp0<0x112, 0xf>(v));             // row_shr:2
+    v = max(v, dpp0<0x114, 0xf>(v));             // row_shr:4
+    v = max(v, dpp0<0x118, 0xf>(v));             // row_shr:8  -> lane 15 of each row
+    v = max(v, dpp0<0x142, 0xa>(v));             // row_bcast:15 into rows 1 and 3
+    v = max(v, dpp0<0x143, 0xc>(v));             // row_bcast:31 into rows 2 and 3
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ u32 wave_add_u32(u32 v)
+{
+    v += dpp0<0x111, 0xf>(v);
+    v += dpp0<0x112, 0xf>(v);
+    v += dpp0<0x114, 0xf>(v);
+    v += dpp0<0x118, 0xf>(v);
+    v += dpp0<0x142, 0xa>(v);
+    v += dpp0<0x143, 0xc>(v);
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+// 64-bit sum of per-lane values below 2^40, as two 32-bit reductions
+__device__ __forceinline__ u64 wave_add_u40(u64 v)
+{
+    const u32 lo = wave_add_u32((u32)v & 0xffffffu);          // 64 * 2^24 fits
+    const u32 hi = wave_add_u32((u32)(v >> 24));              // 64 * 2^16 fits
+    return (u64)lo + ((u64)hi << 24);
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr u32 TILE_U = 4;                        // 16-byte vectors per lane
+constexpr u32 TILE_VEC = 64 * TILE_U;            // vectors per wave: 4 KiB of PCM
+
+// One wave = one 4 KiB tile of one stream, one pass: four non-temporal 16-byte loads per
+// lane, arithmetic, four non-temporal stores, then a short epilogue.  Short-lived waves
+// over small tiles keep the chip-wide access window compact; on MI355X that is worth
+// ~15 % of HBM bandwidth over waves that each stream through tens of KiB
+// (tools/ubench_copy*.hip: 6.3-6.5 TB/s against 5.0-5.4 TB/s for read+write).
+template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU>
+__global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
+{
+    const u32 lane = threadIdx.x;
+    const u32 s = blockIdx.x / a.chunks;         // stream
+    const u32 k = blockIdx.x - s * a.chunks;     // tile inside the stream
 
     const u32 nfr = a.nframes ? a.nframes[s] : a.frames;
     const u32 nsamp = nfr * (u32)C;
     const u32 nfull = nsamp >> 3;                // whole 16-byte vectors
     const u32 ntail = nsamp & 7u;                // samples in the partial last vector
-    const u32 v0 = k * a.vec_per_chunk;
+    const u32 v0 = k * TILE_VEC;
+
+    VuState *vs = DO_VU ? a.vu + s : nullptr;
+    u64 base = 0;
+    if constexpr (DO_VU) {
+        // window position: read from one slot, the stream's first tile writes the other
+        base = vs->samples[a.parity];
+        if (k == 0 && lane == 0)
+            vs->samples[a.parity ^ 1u] = base + nsamp;
+    }
     if (v0 >= nfull + (ntail ? 1u : 0u))
         return;
-    const u32 vend = min(v0 + a.vec_per_chunk, nfull);
 
     const StreamParam *p = a.param + s;
     const u32 magic = p->magic, shift = p->shift, perm2 = p->perm2;
-    u32 g2[C];
-#pragma unroll
-    for (int c = 0; c < C; c++)
-        g2[c] = p->gain2[c];
+    const u32 g2lo = p->gain2[0], g2hi = p->gain2[C - 1];    // gains of the two dword halves
 
     const int16_t *ins = a.in + (u64)s * a.stride;
-    const uint4 *src = reinterpret_cast<const uint4 *>(ins);
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(ins);
     int16_t *outs = WRITE_PCM ? a.out + (u64)s * a.stride : nullptr;
-    uint4 *dst = reinterpret_cast<uint4 *>(outs);
+    u32x4 *dst = reinterpret_cast<u32x4 *>(outs);
     float *f32s = WRITE_F32 ? a.f32 + (u64)s * a.plane * C : nullptr;
 
-    LaneAcc<C, DO_VU> acc;
+    // ---- load: everything this lane will touch, before anything is stored (in-place safe)
+    u32 x[TILE_U][4];
+    bool full[TILE_U], tail[TILE_U];
 #pragma unroll
-    for (int c = 0; c < C; c++) {
-        acc.pow[c] = 0;
-        acc.best[c] = 0;
+    for (u32 u = 0; u < TILE_U; u++) {
+        const u32 v = v0 + 64u * u + lane;
+        full[u] = v < nfull;
+        tail[u] = ntail && v == nfull;
+        u32x4 w = {0, 0, 0, 0};
+        if (full[u])
+            w = __builtin_nontemporal_load(src + v);
+        x[u][0] = w.x; x[u][1] = w.y; x[u][2] = w.z; x[u][3] = w.w;
+        if (tail[u]) {                           // ragged end: sample by sample, zero padded
+            for (u32 j = 0; j < ntail; j++) {
+                const u32 val = (u32)(uint16_t)ins[(u64)v * 8 + j];
+#pragma unroll
+                for (u32 i = 0; i < 4; i++)
+                    if (i == (j >> 1))
+                        x[u][i] |= val << (16u * (j & 1u));
+            }
+        }
     }
 
-    // t counts this lane's vectors inside the chunk; it only has to be monotonic
-    u32 t = 0;
-    for (u32 vb = v0; vb < vend; vb += 256u, t += 4u) {
-        uint4 w[4];
-        bool ok[4];
+    // ---- arithmetic
+    u32 qw[TILE_U][4];                           // packed magnitudes, kept for the epilogue
+    PowAcc pw[2] = {{0, 0, 0}, {0, 0, 0}};
+    u32 best[2] = {0, 0};                        // (magnitude << 16) | (3-u) << 6 | (63-lane)
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const u32 v = vb + 64u * (u32)u + lane;
-            ok[u] = v < vend;
-            w[u] = ok[u] ? src[v] : make_uint4(0, 0, 0, 0);
+    for (u32 u = 0; u < TILE_U; u++) {
+        const u32 v = v0 + 64u * u + lane;
+        u32 o[4], vmax = 0;
+#pragma unroll
+        for (u32 i = 0; i < 4; i++) {
+            if constexpr (C == 2)
+                x[u][i] = __builtin_amdgcn_perm(x[u][i], x[u][i], perm2);   // stereo channel map
+            qw[u][i] = gain2(x[u][i], g2lo, g2hi, magic, shift, o[i]);
+            if constexpr (DO_VU) {
+                vmax = pk_max(vmax, qw[u][i]);
+                pw[0].add(qw[u][i] & 0xffffu);
+                pw[C - 1].add(qw[u][i] >> 16);
+            }
         }
+        if constexpr (DO_VU) {
+            const u32 tag = ((3u - u) << 6) | (63u - lane);
+            const u32 k0 = (vmax << 16) | tag;
+            const u32 k1 = (vmax & 0xffff0000u) | tag;
+            best[0] = max(best[0], k0);
+            best[1] = max(best[1], k1);
+        }
+        if (full[u]) {
+            if constexpr (WRITE_PCM) {
+                const u32x4 ov = {o[0], o[1], o[2], o[3]};
+                __builtin_nontemporal_store(ov, dst + v);
+            }
+            if constexpr (WRITE_F32)
+                store_f32<C>(f32s, a.plane, v, o);
+        } else if (tail[u]) {
+            for (u32 j = 0; j < ntail; j++) {
+                u32 ow = 0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const u32 v = vb + 64u * (u32)u + lane;
-            int x[8], q[8];
-            unpack8<C>(w[u], perm2, x);
-            const u32 tagbase = (ORD_MAX - 8u * (t + (u32)u)) << 1;
-            core8<C, DO_VU>(x, q, g2, magic, shift, tagbase, acc);
-            if (ok[u]) {
+                for (u32 i = 0; i < 4; i++)
+                    if (i == (j >> 1))
+                        ow = o[i];
+                const int q = (int)(short)((ow >> (16u * (j & 1u))) & 0xffffu);
                 if constexpr (WRITE_PCM)
-                    dst[v] = pack8(q);
+                    outs[(u64)v * 8 + j] = (int16_t)q;
                 if constexpr (WRITE_F32)
-                    store_f32<C>(f32s, a.plane, v, q);
+                    f32s[(u64)(j % (u32)C) * a.plane + ((u64)v * 8 + j) / (u32)C] = q * (1.0f / 32768.0f);
             }
         }
     }
 
-    // the partial last vector of the stream (frames*C not a multiple of 8)
-    if (ntail && nfull >= v0 && nfull < v0 + a.vec_per_chunk && lane == ((nfull - v0) & 63u)) {
-        const u32 tt = (nfull - v0) >> 6;
-        int x[8], q[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            x[j] = 0;
-        for (u32 j = 0; j < ntail; j++) {
-            u32 srcj = j;
-            if constexpr (C == 2)                // channel map on single samples
-                srcj = (j & ~1u) | (((perm2 >> ((j & 1u) * 16u)) & 0xffu) >> 1);
-            const int val = ins[(u64)nfull * 8 + srcj];
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++)
-                if ((u32)jj == j)
-                    x[jj] = val;
-        }
-        const u32 tagbase = (ORD_MAX - 8u * tt) << 1;
-        core8<C, DO_VU>(x, q, g2, magic, shift, tagbase, acc);
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
-            if ((u32)jj < ntail) {
-                if constexpr (WRITE_PCM)
-                    outs[(u64)nfull * 8 + jj] = (int16_t)q[jj];
-                if constexpr (WRITE_F32) {
-                    const u32 fr = (nfull * 8u + (u32)jj) / (u32)C, ch = (u32)jj % (u32)C;
-                    f32s[(u64)ch * a.plane + fr] = q[jj] * (1.0f / 32768.0f);
-                }
-            }
-        }
-    }
-
+    // ---- epilogue: one add and one max per channel into the stream's window
     if constexpr (DO_VU) {
-        VuState *vs = a.vu + s;
-        const u64 base = vs->samples;            // written only by k_vu_advance, after us
+        pw[0].flush();
+        pw[1].flush();
+        u64 sum[2];
+        u32 wkey[2];
+        if constexpr (C == 1) {
+            sum[0] = wave_add_u40(pw[0].total + pw[1].total);
+            wkey[0] = wave_max_u32(max(best[0], best[1]));
+            sum[1] = 0;
+            wkey[1] = 0;
+        } else {
+            sum[0] = wave_add_u40(pw[0].total);
+            sum[1] = wave_add_u40(pw[1].total);
+            wkey[0] = wave_max_u32(best[0]);
+            wkey[1] = wave_max_u32(best[1]);
+        }
+        u64 gkey[2] = {0, 0};
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const u32 b = acc.best[c];
-            const u32 mag = b >> 16, tag = b & 0xffffu;
-            const u32 ord = ORD_MAX - (tag >> 1);
-            const u64 idx = base + 8ull * ((u64)v0 + 64ull * (ord >> 3) + lane) + (ord & 7u);
-            const u64 key = wave_max(make_key(mag, idx, tag & 1u));
-            const u64 sum = wave_sum(acc.pow[c]);
-            if (lane == 0) {
-                if (sum)
-                    atomicAdd(&vs->power[c], sum);
-                if (key)
-                    atomicMax(&vs->key[c], key);
+            const u32 mag = wkey[c] >> 16;
+            if (mag == 0)
+                continue;
+            // the winning vector: lowest ordinal, then lowest lane; fetch it into SGPRs
+            const u32 uw = 3u - ((wkey[c] >> 6) & 3u);
+            const u32 lw = 63u - (wkey[c] & 63u);
+            u32 Q[4], X[4];
+#pragma unroll
+            for (u32 u = 0; u < TILE_U; u++) {
+                if (uw == u) {
+#pragma unroll
+                    for (u32 i = 0; i < 4; i++) {
+                        Q[i] = (u32)__builtin_amdgcn_readlane((int)qw[u][i], (int)lw);
+                        X[i] = (u32)__builtin_amdgcn_readlane((int)x[u][i], (int)lw);
+                    }
+                }
             }
+            // first sample of this channel with that magnitude, and its sign
+            u32 first = 8, neg = 0;
+#pragma unroll
+            for (u32 j = 0; j < 8; j++) {
+                if (C == 2 && (j & 1u) != (u32)c)
+                    continue;
+                const u32 m = (Q[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
+                if (m == mag && first == 8) {
+                    first = j;
+                    neg = (X[j >> 1] >> (16u * (j & 1u) + 15u)) & 1u;
+                }
+            }
+            gkey[c] = make_key(mag, base + 8ull * (v0 + 64u * uw + lw) + first, neg);
+        }
+        if (lane < (u32)C) {
+            const u64 ssum = lane == 0 ? sum[0] : sum[1];
+            const u64 skey = lane == 0 ? gkey[0] : gkey[1];
+            if (ssum)
+                atomicAdd(&vs->power[lane], ssum);
+            if (skey)
+                atomicMax(&vs->key[lane], skey);
         }
     }
 }
@@ -297,7 +398,9 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a, u32 blocks_per_s
     const int16_t *ins = a.in + (u64)s * a.stride;
     int16_t *outs = a.out ? a.out + (u64)s * a.stride : nullptr;
     float *f32s = a.f32 ? a.f32 + (u64)s * a.plane * C : nullptr;
-    const u64 base = a.vu ? a.vu[s].samples : 0;
+    const u64 base = a.vu ? a.vu[s].samples[a.parity] : 0;
+    if (a.vu && fb == 0 && threadIdx.x == 0)
+        a.vu[s].samples[a.parity ^ 1u] = base + (u64)nfr * C;
 
     u64 pw[MAX_CH], ky[MAX_CH];
 #pragma unroll
@@ -352,24 +455,15 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a, u32 blocks_per_s
     }
 }
 
-// advances every stream's window position after a run (stream ordered)
-__global__ void k_vu_advance(VuState *vu, const u32 *nframes, u32 frames, u32 streams, u32 channels)
-{
-    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < streams)
-        vu[s].samples += (u64)(nframes ? nframes[s] : frames) * channels;
-}
-
 hipError_t launch_run(const RunArgs &a, hipStream_t st)
 {
     const bool pcm = a.out != nullptr, f32 = a.f32 != nullptr, vu = a.vu != nullptr;
     if (a.streams == 0 || a.frames == 0)
         return hipSuccess;
     if (a.channels <= 2) {
-        const u64 waves = (u64)a.streams * a.chunks;
-        const u32 grid = (u32)((waves + 3) / 4);
+        const u32 grid = a.streams * a.chunks;       // one 64-thread block per 4 KiB tile
 #define CMHIP_FAST(C, P, F, V)                                                     \
-    hipLaunchKernelGGL((k_run_fast<C, P, F, V>), dim3(grid), dim3(256), 0, st, a)
+    hipLaunchKernelGGL((k_run_fast<C, P, F, V>), dim3(grid), dim3(64), 0, st, a)
 #define CMHIP_FAST_C(C)                                                            \
     do {                                                                           \
         if (pcm && !f32 && vu) CMHIP_FAST(C, true, false, true);                   \
@@ -392,14 +486,6 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
             bps = 64u;
         hipLaunchKernelGGL(k_run_generic, dim3(a.streams * bps), dim3(256), 0, st, a, bps);
     }
-    return hipGetLastError();
-}
-
-hipError_t launch_vu_advance(VuState *vu, const u32 *nframes, u32 frames, u32 streams,
-                             u32 channels, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_vu_advance, dim3((streams + 255) / 256), dim3(256), 0, st, vu, nframes,
-                       frames, streams, channels);
     return hipGetLastError();
 }
 
@@ -455,7 +541,7 @@ __global__ __launch_bounds__(64) void k_eq(EqArgs a)
     }
 
     u64 pw = 0, ky = 0;
-    const u64 base = (a.vu && live) ? a.vu[sc].samples : 0;
+    const u64 base = (a.vu && live) ? a.vu[sc].samples[a.parity] : 0;
 
     for (u32 t0 = 0; t0 < nmax; t0 += EQ_TT) {
         // ---- load: two stream rows (2 x 128 B) per wave instruction
@@ -545,6 +631,7 @@ __global__ __launch_bounds__(64) void k_eq(EqArgs a)
             for (int j = 0; j < 4; j++)
                 a.state[s].s[i][j] = stt[i][j];
         if (a.vu) {                                   // this lane is the only writer of stream s
+            a.vu[s].samples[a.parity ^ 1u] = base + nfr;
             a.vu[s].power[0] += pw;
             if (ky > a.vu[s].key[0])
                 a.vu[s].key[0] = ky;
@@ -655,7 +742,7 @@ hipError_t launch_generate(const GenArgs &g, int mode, hipStream_t st)
 //   node key = |peak| << 46 | (2^29-1 - min(frame,2^29-1)) << 17 | (65535 - stream%65536) << 1 | neg
 
 __global__ __launch_bounds__(256) void k_node_partial(const VuState *vu, u32 streams, u32 channels,
-                                                      u64 first_global, u64 global_step,
+                                                      u32 parity, u64 first_global, u64 global_step,
                                                       long long *dst)
 {
     __shared__ u64 lsum[MAX_CH + 1];
@@ -673,7 +760,7 @@ __global__ __launch_bounds__(256) void k_node_partial(const VuState *vu, u32 str
     }
     for (u32 s = blockIdx.x * 256u + threadIdx.x; s < streams; s += gridDim.x * 256u) {
         const u64 gs = first_global + (u64)s * global_step;
-        sum[MAX_CH] += vu[s].samples / channels;
+        sum[MAX_CH] += vu[s].samples[parity] / channels;
 #pragma unroll
         for (u32 c = 0; c < MAX_CH; c++) {
             if (c < channels) {
@@ -713,8 +800,9 @@ __global__ __launch_bounds__(256) void k_node_partial(const VuState *vu, u32 str
     }
 }
 
-hipError_t launch_node_partial(const VuState *vu, u32 streams, u32 channels, uint64_t first_global,
-                               uint64_t global_step, long long *dst, hipStream_t st)
+hipError_t launch_node_partial(const VuState *vu, u32 streams, u32 channels, u32 parity,
+                               uint64_t first_global, uint64_t global_step, long long *dst,
+                               hipStream_t st)
 {
     hipError_t e = hipMemsetAsync(dst, 0, sizeof(long long) * (2 * MAX_CH + 2), st);
     if (e != hipSuccess)
@@ -723,7 +811,7 @@ hipError_t launch_node_partial(const VuState *vu, u32 streams, u32 channels, uin
     if (grid > 256)
         grid = 256;
     hipLaunchKernelGGL(k_node_partial, dim3(grid), dim3(256), 0, st, vu, streams, channels,
-                       first_global, global_step, dst);
+                       parity, first_global, global_step, dst);
     return hipGetLastError();
 }
 

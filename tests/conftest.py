@@ -3,6 +3,7 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  (before the HIP library: torch bundles its own HIP runtime)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

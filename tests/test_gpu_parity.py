@@ -303,7 +303,7 @@ def test_window_is_chunk_size_invariant(gpu, oracle):
     _, r1 = one.vu_result(0)
     many = cm.Batch(1, C, 1000, flags=cm.VU)
     pos = 0
-    for n in (1, 7, 1000, 999, 512, 3, 1000, 1000, 1000, 1000, 670):
+    for n in (1, 7, 1000, 999, 512, 3, 1000, 1000, 1000, 1000, 1000, 670):
         many.upload(0, x[pos * C:(pos + n) * C])
         many.run(n)
         pos += n
