@@ -71,6 +71,7 @@ def main():
 
     import __graft_entry__ as ge
     cm = ge.load_package()
+    from libcoolmic_dsp_amd import shard
 
     if cm.device_count() < 1:
         sys.exit("bench.py: no HIP device; this path has no CPU fallback")
@@ -101,7 +102,9 @@ def main():
     if eq:
         assert b.set_eq(-1, cm.eq3(48000.0)) == 0
     # global stream id of local stream s is rank + s*world (round-robin sharding)
-    b.generate(cm.GEN_NOISE, 12345, T, first_global=rank, global_step=world)
+    n_local, first_global, global_step = shard.shard(S * world, world, rank)
+    assert n_local == S
+    b.generate(cm.GEN_NOISE, 12345, T, first_global=first_global, global_step=global_step)
     b.sync()
 
     has_vu = bool(flags & cm.VU)
@@ -122,8 +125,7 @@ def main():
             if node_vu and world > 1:
                 b.node_partial(node_words.data_ptr(), first_global=rank, global_step=world)
                 b.sync()      # the record is produced on the batch's stream, RCCL uses torch's
-                dist.all_reduce(node_words[:cm.NODE_WORDS // 2], op=dist.ReduceOp.SUM)
-                dist.all_reduce(node_words[cm.NODE_WORDS // 2:], op=dist.ReduceOp.MAX)
+                shard.combine_node_records(dist, node_words)
             if has_vu:
                 if pending:
                     b.vu_collect(results, rcs)       # dB finish of the previous window (host)
@@ -144,10 +146,8 @@ def main():
     kern_ms, launches = b.timing_read()
     b.timing(False)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dt = shard.max_over_ranks(dist, dt, device="cuda")
 
     samples_per_step_rank = S * Cn * T
     total_samples = samples_per_step_rank * world * args.steps
