@@ -16,6 +16,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 extern "C" int coolmic_sine_period(uint_least32_t rate, int16_t *table, size_t *samples);
@@ -67,6 +71,75 @@ struct EventPair {
     hipEvent_t a, b;
 };
 
+// Small persistent worker pool for the dB finish of many windows (log10 + sqrt per
+// channel and stream): with thousands of streams per batch one host thread would take
+// about as long as the GPU needs for the next block.
+struct FinishPool {
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    unsigned generation = 0, remaining = 0;
+    bool stop = false;
+    void (*fn)(void *, unsigned, unsigned) = nullptr;
+    void *arg = nullptr;
+    unsigned total = 0;
+
+    explicit FinishPool(unsigned n)
+    {
+        for (unsigned i = 0; i < n; i++)
+            workers.emplace_back([this, i, n] { loop(i, n); });
+    }
+    ~FinishPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : workers)
+            t.join();
+    }
+    void loop(unsigned idx, unsigned n)
+    {
+        unsigned seen = 0;
+        for (;;) {
+            void (*f)(void *, unsigned, unsigned);
+            void *a;
+            unsigned tot;
+            {
+                std::unique_lock<std::mutex> g(m);
+                cv_work.wait(g, [&] { return stop || generation != seen; });
+                if (stop)
+                    return;
+                seen = generation;
+                f = fn;
+                a = arg;
+                tot = total;
+            }
+            const unsigned lo = (unsigned)((uint64_t)tot * idx / n);
+            const unsigned hi = (unsigned)((uint64_t)tot * (idx + 1) / n);
+            if (hi > lo)
+                f(a, lo, hi);
+            {
+                std::lock_guard<std::mutex> g(m);
+                if (--remaining == 0)
+                    cv_done.notify_one();
+            }
+        }
+    }
+    void run(void (*f)(void *, unsigned, unsigned), void *a, unsigned tot)
+    {
+        std::unique_lock<std::mutex> g(m);
+        fn = f;
+        arg = a;
+        total = tot;
+        remaining = (unsigned)workers.size();
+        generation++;
+        cv_work.notify_all();
+        cv_done.wait(g, [&] { return remaining == 0; });
+    }
+};
+
 struct cmhip_batch {
     cmhip_batch_desc_t d;
     hipStream_t stream;
@@ -77,7 +150,13 @@ struct cmhip_batch {
     int16_t *d_in, *d_out;
     float *d_f32;
     StreamParam *d_param;
-    VuState *d_vu;
+    VuState *d_vu;                         // the window runs accumulate into (= d_vu2[cur])
+    VuState *d_vu2[2];                     // two sets: one accumulates while the other is copied out
+    unsigned int cur;
+    hipStream_t copy_stream;               // snapshots travel here, beside the next run
+    hipEvent_t ev_main, ev_reset[2];
+    bool reset_pending[2];
+    struct FinishPool *pool;
     uint32_t *d_nframes;
     EqParam *d_eq;
     EqState *d_eqstate;
@@ -171,7 +250,18 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     (void)hipFree(b->d_in);
     (void)hipFree(b->d_f32);
     (void)hipFree(b->d_param);
-    (void)hipFree(b->d_vu);
+    (void)hipFree(b->d_vu2[0]);
+    (void)hipFree(b->d_vu2[1]);
+    delete b->pool;
+    if (b->ev_main)
+        (void)hipEventDestroy(b->ev_main);
+    for (int i = 0; i < 2; i++)
+        if (b->ev_reset[i])
+            (void)hipEventDestroy(b->ev_reset[i]);
+    if (b->copy_stream) {
+        (void)hipStreamSynchronize(b->copy_stream);
+        (void)hipStreamDestroy(b->copy_stream);
+    }
     (void)hipFree(b->d_nframes);
     (void)hipFree(b->d_eq);
     (void)hipFree(b->d_eqstate);
@@ -218,8 +308,14 @@ static int batch_init(cmhip_batch_t *b)
         HIP_TRY(hipMemsetAsync(b->d_f32, 0, fbytes, b->stream));
     }
     HIP_TRY(hipMalloc((void **)&b->d_param, S * sizeof(StreamParam)));
-    HIP_TRY(hipMalloc((void **)&b->d_vu, S * sizeof(VuState)));
-    HIP_TRY(hipMemsetAsync(b->d_vu, 0, S * sizeof(VuState), b->stream));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipMalloc((void **)&b->d_vu2[i], S * sizeof(VuState)));
+        HIP_TRY(hipMemsetAsync(b->d_vu2[i], 0, S * sizeof(VuState), b->stream));
+        HIP_TRY(hipEventCreateWithFlags(&b->ev_reset[i], hipEventDisableTiming));
+    }
+    b->d_vu = b->d_vu2[0];
+    HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
     HIP_TRY(hipMalloc((void **)&b->d_nframes, S * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&b->d_sink, sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(b->d_sink, 0, sizeof(unsigned long long), b->stream));
@@ -284,6 +380,13 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->d_f32 = nullptr;
     b->d_param = nullptr;
     b->d_vu = nullptr;
+    b->d_vu2[0] = b->d_vu2[1] = nullptr;
+    b->cur = 0;
+    b->copy_stream = nullptr;
+    b->ev_main = nullptr;
+    b->ev_reset[0] = b->ev_reset[1] = nullptr;
+    b->reset_pending[0] = b->reset_pending[1] = false;
+    b->pool = nullptr;
     b->d_nframes = nullptr;
     b->d_eq = nullptr;
     b->d_eqstate = nullptr;
@@ -780,9 +883,22 @@ extern "C" int cmhip_batch_vu_snapshot(cmhip_batch_t *b)
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     const size_t bytes = b->d.streams * sizeof(VuState);
-    HIP_TRY(hipMemcpyAsync(b->h_snap, b->d_vu, bytes, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipMemsetAsync(b->d_vu, 0, bytes, b->stream));
-    HIP_TRY(hipEventRecord(b->snap_event, b->stream));
+    // The closed windows travel to the host on the copy stream and are cleared there,
+    // while the main stream goes straight on with the next block into the other set.
+    const unsigned i = b->cur;
+    HIP_TRY(hipEventRecord(b->ev_main, b->stream));
+    HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_main, 0));
+    HIP_TRY(hipMemcpyAsync(b->h_snap, b->d_vu2[i], bytes, hipMemcpyDeviceToHost, b->copy_stream));
+    HIP_TRY(hipEventRecord(b->snap_event, b->copy_stream));
+    HIP_TRY(hipMemsetAsync(b->d_vu2[i], 0, bytes, b->copy_stream));
+    HIP_TRY(hipEventRecord(b->ev_reset[i], b->copy_stream));
+    b->reset_pending[i] = true;
+    b->cur = i ^ 1u;
+    b->d_vu = b->d_vu2[b->cur];
+    if (b->reset_pending[b->cur]) {          // the set we switch to must have been cleared
+        HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_reset[b->cur], 0));
+        b->reset_pending[b->cur] = false;
+    }
     b->snap_parity = b->parity;
     b->snap_pending = true;
     return COOLMIC_ERROR_NONE;
@@ -798,10 +914,28 @@ extern "C" int cmhip_batch_vu_collect(cmhip_batch_t *b, coolmic_vumeter_result_t
         return COOLMIC_ERROR_GENERIC;
     HIP_TRY(hipEventSynchronize(b->snap_event));
     b->snap_pending = false;
-    for (unsigned s = 0; s < b->d.streams; s++) {
-        const int r = finish_window(b, b->h_snap[s], b->snap_parity, &out[s]);
-        if (rc)
-            rc[s] = r;
+    struct Job {
+        cmhip_batch_t *b;
+        coolmic_vumeter_result_t *out;
+        int *rc;
+    } job = {b, out, rc};
+    auto body = [](void *p, unsigned lo, unsigned hi) {
+        Job *j = (Job *)p;
+        for (unsigned s = lo; s < hi; s++) {
+            const int r = finish_window(j->b, j->b->h_snap[s], j->b->snap_parity, &j->out[s]);
+            if (j->rc)
+                j->rc[s] = r;
+        }
+    };
+    if (b->d.streams >= 512) {
+        if (!b->pool) {
+            unsigned n = std::thread::hardware_concurrency() / 2;
+            n = n < 1 ? 1 : (n > 8 ? 8 : n);
+            b->pool = new FinishPool(n);
+        }
+        b->pool->run(body, &job, b->d.streams);
+    } else {
+        body(&job, 0, b->d.streams);
     }
     return COOLMIC_ERROR_NONE;
 }
