@@ -639,11 +639,245 @@ __global__ __launch_bounds__(64) void k_eq(EqArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Pipelined EQ (float output only, 1..3 sections): the fast form of config 3.
+//
+// The recurrence allows no parallelism along time and a lane per stream gives only
+// streams/64 waves, so the per-sample work is spread over the waves of a workgroup as a
+// pipeline instead: two loader waves (global load, gain, int16 -> float), one wave per
+// biquad section (lane = stream, 5 FMA-class ops per sample, operands and results through
+// LDS as b128), one store wave.  Each inter-stage buffer holds a 64-stream x 64-frame tile
+// twice; stage k works on block step-k, one __syncthreads() per step.  The section wave is
+// the critical stage: 16 x (ds_read_b128 + 20 VALU + ds_write_b128) per block.
+// Rows are 68 floats: 16-byte aligned and conflict-free for lane-per-row b128 access
+// (bank slot = 17*lane mod 16 over each lane group).
+
+constexpr u32 EP_G = 64;                 // streams per workgroup
+constexpr u32 EP_TB = 64;                // frames per block
+constexpr u32 EP_ROW = 68;               // floats per LDS row
+constexpr u32 EP_TILE = EP_G * EP_ROW;   // floats per buffer slot
+
+__device__ __forceinline__ float biquad_step(float x0, float &x1, float &x2, float &y1, float &y2,
+                                             float b0, float b1, float b2, float na1, float na2)
+{
+    const float f = __builtin_fmaf(b2, x2, __builtin_fmaf(b1, x1, b0 * x0));
+    const float y = __builtin_fmaf(na1, y1, __builtin_fmaf(na2, y2, f));
+    x2 = x1;
+    x1 = x0;
+    y2 = y1;
+    y1 = y;
+    return y;
+}
+
+template <int NSEC>
+__global__ __launch_bounds__((NSEC + 3) * 64) void k_eq_pipe(EqArgs a)
+{
+    extern __shared__ float lds[];       // (NSEC+1) buffers x 2 slots x EP_TILE floats, then 64 counts
+    u32 *nfr_lds = reinterpret_cast<u32 *>(lds + (NSEC + 1) * 2 * EP_TILE);
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const u32 s0 = blockIdx.x * EP_G;
+
+    // frame counts of the 64 streams of this workgroup
+    const u32 sl = s0 + lane;
+    const u32 my_nfr = sl < a.streams ? (a.nframes ? a.nframes[sl] : a.frames) : 0u;
+    if (wave == 0)
+        nfr_lds[lane] = my_nfr;
+    u32 nmax = my_nfr;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        nmax = max(nmax, (u32)__shfl_xor((int)nmax, o, 64));
+    const u32 nblocks = (nmax + EP_TB - 1) / EP_TB;
+    const u32 nsteps = nblocks + NSEC + 1;
+    __syncthreads();
+
+    // ---- role set-up
+    const bool is_loader = wave < 2;
+    const bool is_store = wave == NSEC + 2;
+    const int sec = (int)wave - 2;                       // section index for section waves
+
+    // loaders: lane handles streams r_i = 32*wave + 8*i + lane/8, frames (lane%8)*8 .. +7
+    u32 l_magic[4], l_shift[4], l_g2[4], l_n[4];
+    if (is_loader) {
+#pragma unroll
+        for (u32 i = 0; i < 4; i++) {
+            const u32 r = 32u * wave + 8u * i + (lane >> 3);
+            const u32 sr = min(s0 + r, a.streams - 1);
+            l_magic[i] = a.param[sr].magic;
+            l_shift[i] = a.param[sr].shift;
+            l_g2[i] = a.param[sr].gain2[0];
+            l_n[i] = nfr_lds[r];
+        }
+    }
+    // sections: coefficients and state of this lane's stream
+    float b0 = 0, b1 = 0, b2 = 0, na1 = 0, na2 = 0, x1 = 0, x2 = 0, y1 = 0, y2 = 0;
+    const bool live = sl < a.streams;
+    if (!is_loader && !is_store && live) {
+        const float *c = a.eq[sl].coef[sec];
+        b0 = c[0]; b1 = c[1]; b2 = c[2]; na1 = -c[3]; na2 = -c[4];
+        const float *st = a.state[sl].s[sec];
+        x1 = st[0]; x2 = st[1]; y1 = st[2]; y2 = st[3];
+    }
+
+    // loaders keep the NEXT block's PCM in flight while the pipeline works on this one:
+    // the HBM latency of a block is hidden behind a whole pipeline step
+    u32 wn[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    auto fetch = [&](u32 b) {
+#pragma unroll
+        for (u32 i = 0; i < 4; i++) {
+            const u32 r = 32u * wave + 8u * i + (lane >> 3);
+            const u32 f0 = b * EP_TB + (lane & 7u) * 8u;
+            const int16_t *src = a.in + (u64)(s0 + r) * a.stride + f0;
+            u32x4 v = {0, 0, 0, 0};
+            if (f0 + 8u <= l_n[i])                      // whole vectors only; a ragged end is
+                v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src));   // read when consumed
+            wn[i][0] = v.x; wn[i][1] = v.y; wn[i][2] = v.z; wn[i][3] = v.w;
+        }
+    };
+    if (is_loader && nblocks)
+        fetch(0);
+
+    for (u32 step = 0; step < nsteps; step++) {
+        if (is_loader) {
+            const u32 b = step;
+            if (b < nblocks) {
+                float *X = lds + (b & 1u) * EP_TILE;
+                u32 w[4][4];
+#pragma unroll
+                for (u32 i = 0; i < 4; i++)
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++)
+                        w[i][q] = wn[i][q];
+                if (b + 1 < nblocks)
+                    fetch(b + 1);
+#pragma unroll
+                for (u32 i = 0; i < 4; i++) {
+                    const u32 r = 32u * wave + 8u * i + (lane >> 3);
+                    const u32 t8 = (lane & 7u) * 8u;
+                    const u32 f0 = b * EP_TB + t8;
+                    if (f0 < l_n[i] && f0 + 8u > l_n[i]) {   // ragged end of this stream (rare)
+                        const int16_t *src = a.in + (u64)(s0 + r) * a.stride + f0;
+                        for (u32 j = 0; j < l_n[i] - f0; j++) {
+                            const u32 val = (u32)(uint16_t)src[j];
+#pragma unroll
+                            for (u32 q = 0; q < 4; q++)
+                                if (q == (j >> 1))
+                                    w[i][q] |= val << (16u * (j & 1u));
+                        }
+                    }
+                    float f[8];
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) {
+                        u32 o;
+                        gain2(w[i][q], l_g2[i], l_g2[i], l_magic[i], l_shift[i], o);
+                        f[2 * q] = (float)(int)(short)(o & 0xffffu) * (1.0f / 32768.0f);
+                        f[2 * q + 1] = (float)((int)o >> 16) * (1.0f / 32768.0f);
+                    }
+                    float4 *dstx = reinterpret_cast<float4 *>(X + r * EP_ROW + t8);
+                    dstx[0] = make_float4(f[0], f[1], f[2], f[3]);
+                    dstx[1] = make_float4(f[4], f[5], f[6], f[7]);
+                }
+            }
+        } else if (!is_store) {
+            const u32 stage = (u32)sec + 1u;
+            if (step >= stage && step - stage < nblocks) {
+                const u32 b = step - stage;
+                const float *in = lds + ((u32)sec * 2u + (b & 1u)) * EP_TILE + lane * EP_ROW;
+                float *out = lds + (((u32)sec + 1u) * 2u + (b & 1u)) * EP_TILE + lane * EP_ROW;
+                const u32 done = b * EP_TB;
+                const u32 cnt = my_nfr > done ? min(my_nfr - done, EP_TB) : 0u;
+                if (__all(cnt == EP_TB)) {
+                    // whole row into registers first: 16 LDS reads in flight at once instead
+                    // of one exposed LDS latency per four samples
+                    float4 v[EP_TB / 4];
+#pragma unroll
+                    for (u32 t = 0; t < EP_TB / 4; t++)
+                        v[t] = reinterpret_cast<const float4 *>(in)[t];
+#pragma unroll
+                    for (u32 t = 0; t < EP_TB / 4; t++) {
+                        float4 y;
+                        y.x = biquad_step(v[t].x, x1, x2, y1, y2, b0, b1, b2, na1, na2);
+                        y.y = biquad_step(v[t].y, x1, x2, y1, y2, b0, b1, b2, na1, na2);
+                        y.z = biquad_step(v[t].z, x1, x2, y1, y2, b0, b1, b2, na1, na2);
+                        y.w = biquad_step(v[t].w, x1, x2, y1, y2, b0, b1, b2, na1, na2);
+                        reinterpret_cast<float4 *>(out)[t] = y;
+                    }
+                } else {                                 // some stream ends inside this block
+                    for (u32 t = 0; t < EP_TB; t++) {
+                        float tx1 = x1, tx2 = x2, ty1 = y1, ty2 = y2;
+                        const float y = biquad_step(in[t], tx1, tx2, ty1, ty2, b0, b1, b2, na1, na2);
+                        if (t < cnt) {
+                            x1 = tx1; x2 = tx2; y1 = ty1; y2 = ty2;
+                        }
+                        out[t] = y;
+                    }
+                }
+            }
+        } else {
+            const u32 stage = NSEC + 1;
+            if (step >= stage && step - stage < nblocks) {
+                const u32 b = step - stage;
+                const float *Y = lds + ((u32)NSEC * 2u + (b & 1u)) * EP_TILE;
+#pragma unroll 4
+                for (u32 i = 0; i < 16; i++) {
+                    const u32 r = 4u * i + (lane >> 4);
+                    const u32 t4 = (lane & 15u) * 4u;
+                    const u32 f0 = b * EP_TB + t4;
+                    const u32 n = nfr_lds[r];
+                    const float4 v = *reinterpret_cast<const float4 *>(Y + r * EP_ROW + t4);
+                    float *dstf = a.f32 + (u64)(s0 + r) * a.plane + f0;
+                    if (f0 + 4u <= n) {
+                        typedef float f32x4 __attribute__((ext_vector_type(4)));
+                        const f32x4 vv = {v.x, v.y, v.z, v.w};
+                        __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(dstf));
+                    } else if (f0 < n) {
+                        const float e[4] = {v.x, v.y, v.z, v.w};
+                        for (u32 j = 0; j < n - f0; j++)
+                            dstf[j] = e[j];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (!is_loader && !is_store && live) {
+        float *st = a.state[sl].s[sec];
+        st[0] = x1; st[1] = x2; st[2] = y1; st[3] = y2;
+    }
+}
+
+template <int NSEC>
+static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
+{
+    const size_t lds_bytes = ((size_t)(NSEC + 1) * 2 * EP_TILE) * sizeof(float) + 64 * sizeof(u32);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess)
+            return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((k_eq_pipe<NSEC>), dim3((a.streams + EP_G - 1) / EP_G), dim3((NSEC + 3) * 64),
+                       lds_bytes, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_eq(const EqArgs &a, hipStream_t st)
 {
     const dim3 grid((a.streams + 63) / 64), block(64);
     if (a.streams == 0 || a.frames == 0)
         return hipSuccess;
+    // float output only, 1..3 sections: the pipelined kernel; everything else (int16
+    // result, VU of it, bypass, 4 sections) takes the one-wave-per-tile kernel below
+    if (a.f32 && !a.out && !a.vu) {
+        switch (a.nsec) {
+        case 1: return launch_eq_pipe<1>(a, st);
+        case 2: return launch_eq_pipe<2>(a, st);
+        case 3: return launch_eq_pipe<3>(a, st);
+        default: break;
+        }
+    }
     switch (a.nsec) {
     case 0: hipLaunchKernelGGL(k_eq<0>, grid, block, 0, st, a); break;
     case 1: hipLaunchKernelGGL(k_eq<1>, grid, block, 0, st, a); break;

@@ -97,3 +97,44 @@ def test_eq_config3_shape_sampled(gpu, oracle):
         gf = b.download_f32(s, 0, T)
         assert np.array_equal(gf.view(np.uint32), wf.view(np.uint32)), s
     b.close()
+
+
+@pytest.mark.parametrize("nsec", [1, 2, 3])
+def test_eq_pipelined_kernel_ragged_and_state_carry(gpu, oracle, nsec):
+    """float-only batches take the pipelined kernel (k_eq_pipe): ragged stream ends inside
+    and across 64-frame blocks, streams of length 0, three launches with carried state"""
+    cm = gpu
+    rng = np.random.default_rng(100 + nsec)
+    S, T = 130, 333                      # 3 workgroups (64 + 64 + 2 streams), 6 blocks
+    coef = cm.eq3(48000.0)[: 5 * nsec]
+    b = cm.Batch(S, 1, T, flags=cm.EQ | cm.OUT_F32)
+    assert b.set_eq(-1, coef) == 0
+    gains = []
+    for s in range(S):
+        ga = None if s % 4 == 0 else (1, 1000, [int(rng.integers(200, 2500))])
+        if ga:
+            assert b.set_gain(s, *ga) == 0
+        gains.append(ga)
+    all_lens = []
+    for k in range(3):
+        lens = [int(v) for v in rng.integers(0, T + 1, S)]
+        lens[0], lens[1], lens[2], lens[3], lens[64], lens[129] = T, 0, 1, 64, 65, T
+        if k == 1:
+            lens = [T] * S               # a launch where no stream is ragged
+        all_lens.append(lens)
+    blocks = [[rng.integers(-32768, 32768, all_lens[k][s]).astype(np.int16) for k in range(3)]
+              for s in range(S)]
+    got = [[None] * 3 for _ in range(S)]
+    for k in range(3):
+        for s in range(S):
+            if all_lens[k][s]:
+                b.upload(s, blocks[s][k])
+        b.run(T, frames_per_stream=all_lens[k])
+        for s in range(S):
+            got[s][k] = b.download_f32(s, 0, all_lens[k][s])
+    for s in range(S):
+        want = _oracle_eq(oracle, coef, nsec, gains[s], blocks[s])
+        for k in range(3):
+            wf, _ = want[k]
+            assert np.array_equal(got[s][k].view(np.uint32), wf.view(np.uint32)), (nsec, s, k)
+    b.close()
