@@ -15,6 +15,7 @@
 //   VU       ref: src/vumeter.c:161-177     first max-|x| peak, sum of squares
 //   float    ref: src/enc_vorbis.c:108-115  x / 32768.f, planar
 #include "cmhip_internal.h"
+#include <stdlib.h>
 
 namespace cmhip {
 
@@ -644,18 +645,20 @@ __global__ __launch_bounds__(64) void k_eq(EqArgs a)
 //
 // The recurrence allows no parallelism along time and a lane per stream gives only
 // streams/64 waves, so the per-sample work is spread over the waves of a workgroup as a
-// pipeline instead: two loader waves (global load, gain, int16 -> float), one wave per
-// biquad section (lane = stream, 5 FMA-class ops per sample, operands and results through
-// LDS as b128), one store wave.  Each inter-stage buffer holds a 64-stream x 64-frame tile
-// twice; stage k works on block step-k, one __syncthreads() per step.  The section wave is
-// the critical stage: 16 x (ds_read_b128 + 20 VALU + ds_write_b128) per block.
-// Rows are 68 floats: 16-byte aligned and conflict-free for lane-per-row b128 access
-// (bank slot = 17*lane mod 16 over each lane group).
+// pipeline: four loader waves (global load, gain, int16 -> float), one wave per biquad
+// section (lane = stream; operands and results through LDS as b128), one store wave.
+// Each inter-stage buffer holds a 32-stream x 64-frame tile twice; stage k works on
+// block step-k, one __syncthreads() per step.
+//
+// Sizing, from stage ablation on MI355X: a CU moves ~10 B/clk of global traffic, so a
+// workgroup takes 32 streams (12 KiB per step) and config 3 spreads over all 256 CUs;
+// a section wave needs ~350 issue slots per block and must not share its SIMD with
+// another heavy wave, so the roles are ordered section,section,section,store,loader x4:
+// waves i and i+4 land on the same SIMD, pairing each section wave with one light loader.
+// Rows are 68 floats: 16-byte aligned and conflict-free for lane-per-row b128 access.
 
-constexpr u32 EP_G = 64;                 // streams per workgroup
 constexpr u32 EP_TB = 64;                // frames per block
 constexpr u32 EP_ROW = 68;               // floats per LDS row
-constexpr u32 EP_TILE = EP_G * EP_ROW;   // floats per buffer slot
 
 __device__ __forceinline__ float biquad_step(float x0, float &x1, float &x2, float &y1, float &y2,
                                              float b0, float b1, float b2, float na1, float na2)
@@ -669,49 +672,54 @@ __device__ __forceinline__ float biquad_step(float x0, float &x1, float &x2, flo
     return y;
 }
 
-template <int NSEC>
-__global__ __launch_bounds__((NSEC + 3) * 64) void k_eq_pipe(EqArgs a)
+// G = streams per workgroup (8, 16 or 32): one loader wave per 8 streams.  Small groups
+// mean several independent pipelines per CU, which hides the barrier and LDS latencies of
+// each other; the section waves then run with G of 64 lanes doing distinct work.
+template <int NSEC, int G>
+__global__ __launch_bounds__((NSEC + 1 + G / 8) * 64) void k_eq_pipe(EqArgs a)
 {
-    extern __shared__ float lds[];       // (NSEC+1) buffers x 2 slots x EP_TILE floats, then 64 counts
+    constexpr u32 EP_G = G;
+    constexpr u32 EP_TILE = EP_G * EP_ROW;   // floats per buffer slot
+    extern __shared__ float lds[];       // (NSEC+1) buffers x 2 slots x EP_TILE floats, then G counts
     u32 *nfr_lds = reinterpret_cast<u32 *>(lds + (NSEC + 1) * 2 * EP_TILE);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const u32 s0 = blockIdx.x * EP_G;
 
-    // frame counts of the 64 streams of this workgroup
-    const u32 sl = s0 + lane;
-    const u32 my_nfr = sl < a.streams ? (a.nframes ? a.nframes[sl] : a.frames) : 0u;
-    if (wave == 0)
+    // roles by wave index (see the SIMD pairing note above)
+    const bool is_section = wave < (u32)NSEC;
+    const bool is_loader = wave > (u32)NSEC;
+    const u32 lw = wave - (u32)NSEC - 1u;                 // loader index 0..G/8-1
+    const u32 sec = wave;                                 // section index for section waves
+
+    // frame counts of the G streams; lanes beyond G mirror the first G
+    const u32 row = lane % EP_G;
+    const u32 sl = s0 + row;
+    const bool live = sl < a.streams;
+    const u32 my_nfr = live ? (a.nframes ? a.nframes[sl] : a.frames) : 0u;
+    if (wave == 0 && lane < EP_G)
         nfr_lds[lane] = my_nfr;
     u32 nmax = my_nfr;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
+    for (int o = G / 2; o > 0; o >>= 1)
         nmax = max(nmax, (u32)__shfl_xor((int)nmax, o, 64));
     const u32 nblocks = (nmax + EP_TB - 1) / EP_TB;
     const u32 nsteps = nblocks + NSEC + 1;
     __syncthreads();
 
-    // ---- role set-up
-    const bool is_loader = wave < 2;
-    const bool is_store = wave == NSEC + 2;
-    const int sec = (int)wave - 2;                       // section index for section waves
-
-    // loaders: lane handles streams r_i = 32*wave + 8*i + lane/8, frames (lane%8)*8 .. +7
-    u32 l_magic[4], l_shift[4], l_g2[4], l_n[4];
+    // loaders: lane handles stream r = 8*lw + lane/8, frames (lane%8)*8 .. +7 of each block
+    const u32 l_r = 8u * lw + (lane >> 3);
+    const u32 l_t8 = (lane & 7u) * 8u;
+    u32 l_magic = 0, l_shift = 0, l_g2 = 0, l_n = 0;
     if (is_loader) {
-#pragma unroll
-        for (u32 i = 0; i < 4; i++) {
-            const u32 r = 32u * wave + 8u * i + (lane >> 3);
-            const u32 sr = min(s0 + r, a.streams - 1);
-            l_magic[i] = a.param[sr].magic;
-            l_shift[i] = a.param[sr].shift;
-            l_g2[i] = a.param[sr].gain2[0];
-            l_n[i] = nfr_lds[r];
-        }
+        const u32 sr = min(s0 + l_r, a.streams - 1);
+        l_magic = a.param[sr].magic;
+        l_shift = a.param[sr].shift;
+        l_g2 = a.param[sr].gain2[0];
+        l_n = nfr_lds[l_r];
     }
     // sections: coefficients and state of this lane's stream
     float b0 = 0, b1 = 0, b2 = 0, na1 = 0, na2 = 0, x1 = 0, x2 = 0, y1 = 0, y2 = 0;
-    const bool live = sl < a.streams;
-    if (!is_loader && !is_store && live) {
+    if (is_section && live) {
         const float *c = a.eq[sl].coef[sec];
         b0 = c[0]; b1 = c[1]; b2 = c[2]; na1 = -c[3]; na2 = -c[4];
         const float *st = a.state[sl].s[sec];
@@ -720,18 +728,14 @@ __global__ __launch_bounds__((NSEC + 3) * 64) void k_eq_pipe(EqArgs a)
 
     // loaders keep the NEXT block's PCM in flight while the pipeline works on this one:
     // the HBM latency of a block is hidden behind a whole pipeline step
-    u32 wn[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    u32x4 wn = {0, 0, 0, 0};
     auto fetch = [&](u32 b) {
-#pragma unroll
-        for (u32 i = 0; i < 4; i++) {
-            const u32 r = 32u * wave + 8u * i + (lane >> 3);
-            const u32 f0 = b * EP_TB + (lane & 7u) * 8u;
-            const int16_t *src = a.in + (u64)(s0 + r) * a.stride + f0;
-            u32x4 v = {0, 0, 0, 0};
-            if (f0 + 8u <= l_n[i])                      // whole vectors only; a ragged end is
-                v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src));   // read when consumed
-            wn[i][0] = v.x; wn[i][1] = v.y; wn[i][2] = v.z; wn[i][3] = v.w;
-        }
+        const u32 f0 = b * EP_TB + l_t8;
+        const int16_t *src = a.in + (u64)(s0 + l_r) * a.stride + f0;
+        u32x4 v = {0, 0, 0, 0};
+        if (f0 + 8u <= l_n)                               // whole vectors only; a ragged end is
+            v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src));   // read when consumed
+        wn = v;
     };
     if (is_loader && nblocks)
         fetch(0);
@@ -741,48 +745,38 @@ __global__ __launch_bounds__((NSEC + 3) * 64) void k_eq_pipe(EqArgs a)
             const u32 b = step;
             if (b < nblocks) {
                 float *X = lds + (b & 1u) * EP_TILE;
-                u32 w[4][4];
-#pragma unroll
-                for (u32 i = 0; i < 4; i++)
-#pragma unroll
-                    for (u32 q = 0; q < 4; q++)
-                        w[i][q] = wn[i][q];
+                u32 w[4] = {wn.x, wn.y, wn.z, wn.w};
                 if (b + 1 < nblocks)
                     fetch(b + 1);
+                const u32 f0 = b * EP_TB + l_t8;
+                if (f0 < l_n && f0 + 8u > l_n) {          // ragged end of this stream (rare)
+                    const int16_t *src = a.in + (u64)(s0 + l_r) * a.stride + f0;
+                    for (u32 j = 0; j < l_n - f0; j++) {
+                        const u32 val = (u32)(uint16_t)src[j];
 #pragma unroll
-                for (u32 i = 0; i < 4; i++) {
-                    const u32 r = 32u * wave + 8u * i + (lane >> 3);
-                    const u32 t8 = (lane & 7u) * 8u;
-                    const u32 f0 = b * EP_TB + t8;
-                    if (f0 < l_n[i] && f0 + 8u > l_n[i]) {   // ragged end of this stream (rare)
-                        const int16_t *src = a.in + (u64)(s0 + r) * a.stride + f0;
-                        for (u32 j = 0; j < l_n[i] - f0; j++) {
-                            const u32 val = (u32)(uint16_t)src[j];
-#pragma unroll
-                            for (u32 q = 0; q < 4; q++)
-                                if (q == (j >> 1))
-                                    w[i][q] |= val << (16u * (j & 1u));
-                        }
+                        for (u32 q = 0; q < 4; q++)
+                            if (q == (j >> 1))
+                                w[q] |= val << (16u * (j & 1u));
                     }
-                    float f[8];
-#pragma unroll
-                    for (u32 q = 0; q < 4; q++) {
-                        u32 o;
-                        gain2(w[i][q], l_g2[i], l_g2[i], l_magic[i], l_shift[i], o);
-                        f[2 * q] = (float)(int)(short)(o & 0xffffu) * (1.0f / 32768.0f);
-                        f[2 * q + 1] = (float)((int)o >> 16) * (1.0f / 32768.0f);
-                    }
-                    float4 *dstx = reinterpret_cast<float4 *>(X + r * EP_ROW + t8);
-                    dstx[0] = make_float4(f[0], f[1], f[2], f[3]);
-                    dstx[1] = make_float4(f[4], f[5], f[6], f[7]);
                 }
+                float f[8];
+#pragma unroll
+                for (u32 q = 0; q < 4; q++) {
+                    u32 o;
+                    gain2(w[q], l_g2, l_g2, l_magic, l_shift, o);
+                    f[2 * q] = (float)(int)(short)(o & 0xffffu) * (1.0f / 32768.0f);
+                    f[2 * q + 1] = (float)((int)o >> 16) * (1.0f / 32768.0f);
+                }
+                float4 *dstx = reinterpret_cast<float4 *>(X + l_r * EP_ROW + l_t8);
+                dstx[0] = make_float4(f[0], f[1], f[2], f[3]);
+                dstx[1] = make_float4(f[4], f[5], f[6], f[7]);
             }
-        } else if (!is_store) {
-            const u32 stage = (u32)sec + 1u;
+        } else if (is_section) {
+            const u32 stage = sec + 1u;
             if (step >= stage && step - stage < nblocks) {
                 const u32 b = step - stage;
-                const float *in = lds + ((u32)sec * 2u + (b & 1u)) * EP_TILE + lane * EP_ROW;
-                float *out = lds + (((u32)sec + 1u) * 2u + (b & 1u)) * EP_TILE + lane * EP_ROW;
+                const float *in = lds + (sec * 2u + (b & 1u)) * EP_TILE + row * EP_ROW;
+                float *out = lds + ((sec + 1u) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW;
                 const u32 done = b * EP_TB;
                 const u32 cnt = my_nfr > done ? min(my_nfr - done, EP_TB) : 0u;
                 if (__all(cnt == EP_TB)) {
@@ -817,8 +811,8 @@ __global__ __launch_bounds__((NSEC + 3) * 64) void k_eq_pipe(EqArgs a)
             if (step >= stage && step - stage < nblocks) {
                 const u32 b = step - stage;
                 const float *Y = lds + ((u32)NSEC * 2u + (b & 1u)) * EP_TILE;
-#pragma unroll 4
-                for (u32 i = 0; i < 16; i++) {
+#pragma unroll
+                for (u32 i = 0; i < EP_G / 4; i++) {
                     const u32 r = 4u * i + (lane >> 4);
                     const u32 t4 = (lane & 15u) * 4u;
                     const u32 f0 = b * EP_TB + t4;
@@ -840,27 +834,39 @@ __global__ __launch_bounds__((NSEC + 3) * 64) void k_eq_pipe(EqArgs a)
         __syncthreads();
     }
 
-    if (!is_loader && !is_store && live) {
+    if (is_section && live && lane < EP_G) {
         float *st = a.state[sl].s[sec];
         st[0] = x1; st[1] = x2; st[2] = y1; st[3] = y2;
     }
 }
 
-template <int NSEC>
+template <int NSEC, int G>
 static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
 {
-    const size_t lds_bytes = ((size_t)(NSEC + 1) * 2 * EP_TILE) * sizeof(float) + 64 * sizeof(u32);
+    const size_t lds_bytes = ((size_t)(NSEC + 1) * 2 * G * EP_ROW) * sizeof(float) + G * sizeof(u32);
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess)
             return e;
         configured = true;
     }
-    hipLaunchKernelGGL((k_eq_pipe<NSEC>), dim3((a.streams + EP_G - 1) / EP_G), dim3((NSEC + 3) * 64),
+    hipLaunchKernelGGL((k_eq_pipe<NSEC, G>), dim3((a.streams + G - 1) / G), dim3((NSEC + 1 + G / 8) * 64),
                        lds_bytes, st, a);
     return hipGetLastError();
+}
+
+template <int NSEC>
+static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st)
+{
+    const char *e = getenv("CMHIP_EQ_G");                 // tuning knob
+    const int g = e ? atoi(e) : 8;
+    if (g == 32)
+        return launch_eq_pipe<NSEC, 32>(a, st);
+    if (g == 16)
+        return launch_eq_pipe<NSEC, 16>(a, st);
+    return launch_eq_pipe<NSEC, 8>(a, st);
 }
 
 hipError_t launch_eq(const EqArgs &a, hipStream_t st)
@@ -872,9 +878,9 @@ hipError_t launch_eq(const EqArgs &a, hipStream_t st)
     // result, VU of it, bypass, 4 sections) takes the one-wave-per-tile kernel below
     if (a.f32 && !a.out && !a.vu) {
         switch (a.nsec) {
-        case 1: return launch_eq_pipe<1>(a, st);
-        case 2: return launch_eq_pipe<2>(a, st);
-        case 3: return launch_eq_pipe<3>(a, st);
+        case 1: return launch_eq_pipe_g<1>(a, st);
+        case 2: return launch_eq_pipe_g<2>(a, st);
+        case 3: return launch_eq_pipe_g<3>(a, st);
         default: break;
         }
     }
