@@ -861,7 +861,7 @@ template <int NSEC>
 static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st)
 {
     const char *e = getenv("CMHIP_EQ_G");                 // tuning knob
-    const int g = e ? atoi(e) : 8;
+    const int g = e ? atoi(e) : 32;                       // 32: best on MI355X
     if (g == 32)
         return launch_eq_pipe<NSEC, 32>(a, st);
     if (g == 16)
