@@ -168,7 +168,7 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "kernel": "k_eq" if eq else "k_run_fast", "kernel_avg_ms": round(kern_avg_ms, 4),
+        "kernel": "k_eq_pipe" if eq else "k_run_fast", "kernel_avg_ms": round(kern_avg_ms, 4),
         "launches": launches, "algorithmic_bytes_per_sample": bps,
         "algorithmic_bytes_per_launch": samples_per_step_rank * bps,
     }

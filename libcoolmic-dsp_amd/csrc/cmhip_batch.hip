@@ -708,14 +708,6 @@ static int flush_params(cmhip_batch_t *b)
     return COOLMIC_ERROR_NONE;
 }
 
-// one wave per 4 KiB tile: 256 vectors of 16 bytes
-static uint32_t tiles_per_stream(const cmhip_batch_t *b, size_t frames)
-{
-    const uint64_t nvec = ((uint64_t)frames * b->d.channels + 7) / 8;
-    const uint64_t t = (nvec + 255) / 256;
-    return (uint32_t)(t ? t : 1);
-}
-
 static EventPair take_events(cmhip_batch_t *b)
 {
     EventPair e{};
@@ -788,10 +780,8 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.channels = b->d.channels;
         a.stride = b->stride;
         a.plane = b->plane;
-        a.chunks = tiles_per_stream(b, frames);
+        a.chunks = 0;                      // the launcher sizes the tiles per kernel variant
         a.parity = b->parity;
-        if ((uint64_t)a.chunks * a.streams >= (1ull << 31))
-            return fail(COOLMIC_ERROR_INVAL, "run: too many tiles for one launch");
         HIP_TRY(launch_run(a, b->stream));
     }
     if (b->timing) {

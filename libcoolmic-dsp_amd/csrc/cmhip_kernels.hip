@@ -201,17 +201,20 @@ __device__ __forceinline__ u64 wave_add_u40(u64 v)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr u32 TILE_U = 4;                        // 16-byte vectors per lane
+constexpr u32 TILE_U = 4;                        // 16-byte vectors per lane when PCM is written
 constexpr u32 TILE_VEC = 64 * TILE_U;            // vectors per wave: 4 KiB of PCM
+constexpr u32 TILE_U_VUONLY = 16;                // read-only runs: 8 KiB tiles (epilogue amortised)
 
 // One wave = one 4 KiB tile of one stream, one pass: four non-temporal 16-byte loads per
 // lane, arithmetic, four non-temporal stores, then a short epilogue.  Short-lived waves
 // over small tiles keep the chip-wide access window compact; on MI355X that is worth
 // ~15 % of HBM bandwidth over waves that each stream through tens of KiB
 // (tools/ubench_copy*.hip: 6.3-6.5 TB/s against 5.0-5.4 TB/s for read+write).
-template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU>
+template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U>
 __global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
 {
+    constexpr u32 TILE_U = U;
+    constexpr u32 TILE_VEC = 64 * TILE_U;
     const u32 lane = threadIdx.x;
     const u32 s = blockIdx.x / a.chunks;         // stream
     const u32 k = blockIdx.x - s * a.chunks;     // tile inside the stream
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
     // ---- arithmetic
     u32 qw[TILE_U][4];                           // packed magnitudes, kept for the epilogue
     PowAcc pw[2] = {{0, 0, 0}, {0, 0, 0}};
-    u32 best[2] = {0, 0};                        // (magnitude << 16) | (3-u) << 6 | (63-lane)
+    u32 best[2] = {0, 0};                        // (magnitude << 16) | (U-1-u) << 6 | (63-lane)
 #pragma unroll
     for (u32 u = 0; u < TILE_U; u++) {
         const u32 v = v0 + 64u * u + lane;
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
             }
         }
         if constexpr (DO_VU) {
-            const u32 tag = ((3u - u) << 6) | (63u - lane);
+            const u32 tag = ((TILE_U - 1u - u) << 6) | (63u - lane);
             const u32 k0 = (vmax << 16) | tag;
             const u32 k1 = (vmax & 0xffff0000u) | tag;
             best[0] = max(best[0], k0);
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
             if (mag == 0)
                 continue;
             // the winning vector: lowest ordinal, then lowest lane; fetch it into SGPRs
-            const u32 uw = 3u - ((wkey[c] >> 6) & 3u);
+            const u32 uw = TILE_U - 1u - ((wkey[c] >> 6) & (TILE_U - 1u));
             const u32 lw = 63u - (wkey[c] & 63u);
             u32 Q[4], X[4];
 #pragma unroll
@@ -462,9 +465,19 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
     if (a.streams == 0 || a.frames == 0)
         return hipSuccess;
     if (a.channels <= 2) {
-        const u32 grid = a.streams * a.chunks;       // one 64-thread block per 4 KiB tile
+        // one 64-thread block per tile: 4 KiB when PCM or float is written, 8 KiB read-only
+        RunArgs b = a;
+        const u32 tile_u = (pcm || f32) ? TILE_U : TILE_U_VUONLY;
+        const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
+        b.chunks = (u32)((nvec + 64ull * tile_u - 1) / (64ull * tile_u));
+        if (b.chunks == 0)
+            b.chunks = 1;
+        if ((u64)b.chunks * a.streams >= (1ull << 31))
+            return hipErrorInvalidValue;
+        const u32 grid = a.streams * b.chunks;
 #define CMHIP_FAST(C, P, F, V)                                                     \
-    hipLaunchKernelGGL((k_run_fast<C, P, F, V>), dim3(grid), dim3(64), 0, st, a)
+    hipLaunchKernelGGL((k_run_fast<C, P, F, V, ((P) || (F)) ? (int)TILE_U : (int)TILE_U_VUONLY>), \
+                       dim3(grid), dim3(64), 0, st, b)
 #define CMHIP_FAST_C(C)                                                            \
     do {                                                                           \
         if (pcm && !f32 && vu) CMHIP_FAST(C, true, false, true);                   \
@@ -1057,35 +1070,57 @@ hipError_t launch_node_partial(const VuState *vu, u32 streams, u32 channels, u32
 
 // ---------------------------------------------------------------------------
 // Plain HBM ceilings over the same buffers: read-only sum, and copy.
+// Same access shape as k_run_fast -- one short-lived wave per 4 KiB tile, four
+// non-temporal 16-byte accesses per lane -- with no arithmetic, so the numbers are what
+// the memory system gives this pattern (the best of the shapes in tools/ubench_copy*.hip).
 
-__global__ __launch_bounds__(256) void k_ceiling_read(const uint4 *src, u64 nvec, u64 *sink)
+__global__ __launch_bounds__(64) void k_ceiling_read(const u32x4 *src, u64 nvec, u64 *sink)
 {
+    const u64 v0 = (u64)blockIdx.x * TILE_VEC + threadIdx.x;
     u32 acc = 0;
-    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < nvec; i += (u64)gridDim.x * 256u) {
-        const uint4 w = src[i];
-        acc += w.x ^ w.y ^ w.z ^ w.w;
+#pragma unroll
+    for (u32 u = 0; u < TILE_U; u++) {
+        const u64 i = v0 + 64u * u;
+        if (i < nvec) {
+            const u32x4 w = __builtin_nontemporal_load(src + i);
+            acc += w.x ^ w.y ^ w.z ^ w.w;
+        }
     }
     if (acc == 0x9e3779b9u)          // practically never: keeps the loads alive
         atomicAdd(sink, 1ull);
 }
 
-__global__ __launch_bounds__(256) void k_ceiling_copy(const uint4 *src, uint4 *dst, u64 nvec)
+__global__ __launch_bounds__(64) void k_ceiling_copy(const u32x4 *src, u32x4 *dst, u64 nvec)
 {
-    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < nvec; i += (u64)gridDim.x * 256u)
-        dst[i] = src[i];
+    const u64 v0 = (u64)blockIdx.x * TILE_VEC + threadIdx.x;
+    u32x4 w[TILE_U];
+#pragma unroll
+    for (u32 u = 0; u < TILE_U; u++) {
+        const u64 i = v0 + 64u * u;
+        if (i < nvec)
+            w[u] = __builtin_nontemporal_load(src + i);
+    }
+#pragma unroll
+    for (u32 u = 0; u < TILE_U; u++) {
+        const u64 i = v0 + 64u * u;
+        if (i < nvec)
+            __builtin_nontemporal_store(w[u], dst + i);
+    }
 }
 
 hipError_t launch_ceiling(int mode, const void *src, void *dst, size_t bytes, u64 *sink,
                           hipStream_t st)
 {
     const u64 nvec = bytes / 16;
-    const u32 grid = 256 * 8;
+    const u64 tiles = (nvec + TILE_VEC - 1) / TILE_VEC;
+    if (tiles == 0 || tiles >= (1ull << 31))
+        return hipErrorInvalidValue;
     if (mode == 0)
-        hipLaunchKernelGGL(k_ceiling_read, dim3(grid), dim3(256), 0, st,
-                           reinterpret_cast<const uint4 *>(src), nvec, sink);
+        hipLaunchKernelGGL(k_ceiling_read, dim3((u32)tiles), dim3(64), 0, st,
+                           reinterpret_cast<const u32x4 *>(src), nvec, sink);
     else
-        hipLaunchKernelGGL(k_ceiling_copy, dim3(grid), dim3(256), 0, st,
-                           reinterpret_cast<const uint4 *>(src), reinterpret_cast<uint4 *>(dst),
+        hipLaunchKernelGGL(k_ceiling_copy, dim3((u32)tiles), dim3(64), 0, st,
+                           reinterpret_cast<const u32x4 *>(src), reinterpret_cast<u32x4 *>(dst),
                            nvec);
     return hipGetLastError();
 }
