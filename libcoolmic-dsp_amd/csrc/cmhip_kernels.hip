@@ -203,7 +203,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr u32 TILE_U = 4;                        // 16-byte vectors per lane when PCM is written
 constexpr u32 TILE_VEC = 64 * TILE_U;            // vectors per wave: 4 KiB of PCM
-constexpr u32 TILE_U_VUONLY = 16;                // read-only runs: 8 KiB tiles (epilogue amortised)
+// read-only runs take bigger tiles to amortise the epilogue (picked per channel count from
+// interleaved A/B runs, tools/ab_tiles.py); $CMHIP_VU_TILE (4, 8, 16) overrides for tuning
+constexpr u32 TILE_U_VUONLY_MONO = 8;
+constexpr u32 TILE_U_VUONLY_STEREO = 16;
 
 // One wave = one 4 KiB tile of one stream, one pass: four non-temporal 16-byte loads per
 // lane, arithmetic, four non-temporal stores, then a short epilogue.  Short-lived waves
@@ -465,9 +468,18 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
     if (a.streams == 0 || a.frames == 0)
         return hipSuccess;
     if (a.channels <= 2) {
-        // one 64-thread block per tile: 4 KiB when PCM or float is written, 8 KiB read-only
+        // one 64-thread block per tile: 4 KiB when PCM or float is written, larger read-only
         RunArgs b = a;
-        const u32 tile_u = (pcm || f32) ? TILE_U : TILE_U_VUONLY;
+        u32 tile_u = TILE_U;
+        if (!pcm && !f32) {
+            tile_u = a.channels == 1 ? TILE_U_VUONLY_MONO : TILE_U_VUONLY_STEREO;
+            const char *e = getenv("CMHIP_VU_TILE");
+            if (e) {
+                const int v = atoi(e);
+                if (v == 4 || v == 8 || v == 16)
+                    tile_u = (u32)v;
+            }
+        }
         const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
         b.chunks = (u32)((nvec + 64ull * tile_u - 1) / (64ull * tile_u));
         if (b.chunks == 0)
@@ -475,18 +487,19 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
         if ((u64)b.chunks * a.streams >= (1ull << 31))
             return hipErrorInvalidValue;
         const u32 grid = a.streams * b.chunks;
-#define CMHIP_FAST(C, P, F, V)                                                     \
-    hipLaunchKernelGGL((k_run_fast<C, P, F, V, ((P) || (F)) ? (int)TILE_U : (int)TILE_U_VUONLY>), \
-                       dim3(grid), dim3(64), 0, st, b)
+#define CMHIP_FAST(C, P, F, V, U)                                                  \
+    hipLaunchKernelGGL((k_run_fast<C, P, F, V, U>), dim3(grid), dim3(64), 0, st, b)
 #define CMHIP_FAST_C(C)                                                            \
     do {                                                                           \
-        if (pcm && !f32 && vu) CMHIP_FAST(C, true, false, true);                   \
-        else if (!pcm && !f32 && vu) CMHIP_FAST(C, false, false, true);            \
-        else if (pcm && !f32 && !vu) CMHIP_FAST(C, true, false, false);            \
-        else if (pcm && f32 && vu) CMHIP_FAST(C, true, true, true);                \
-        else if (!pcm && f32 && vu) CMHIP_FAST(C, false, true, true);              \
-        else if (pcm && f32 && !vu) CMHIP_FAST(C, true, true, false);              \
-        else if (!pcm && f32 && !vu) CMHIP_FAST(C, false, true, false);            \
+        if (pcm && !f32 && vu) CMHIP_FAST(C, true, false, true, 4);                \
+        else if (!pcm && !f32 && vu && tile_u == 4) CMHIP_FAST(C, false, false, true, 4);   \
+        else if (!pcm && !f32 && vu && tile_u == 8) CMHIP_FAST(C, false, false, true, 8);   \
+        else if (!pcm && !f32 && vu) CMHIP_FAST(C, false, false, true, 16);        \
+        else if (pcm && !f32 && !vu) CMHIP_FAST(C, true, false, false, 4);         \
+        else if (pcm && f32 && vu) CMHIP_FAST(C, true, true, true, 4);             \
+        else if (!pcm && f32 && vu) CMHIP_FAST(C, false, true, true, 4);           \
+        else if (pcm && f32 && !vu) CMHIP_FAST(C, true, true, false, 4);           \
+        else if (!pcm && f32 && !vu) CMHIP_FAST(C, false, true, false, 4);         \
     } while (0)
         if (a.channels == 1)
             CMHIP_FAST_C(1);
