@@ -1,0 +1,71 @@
+/*
+ * group.h -- many transform -> vumeter pipelines served by ONE launch per block.
+ *
+ * Not in the reference.  A host that runs thousands of capture streams builds one
+ * coolmic_group_t instead of thousands of coolmic_transform_t / coolmic_vumeter_t
+ * pairs; every stream keeps the reference's operator interface on both sides:
+ *
+ *   upstream:    any coolmic_iohandle_t per stream (snddev, file, user callback)
+ *   downstream:  coolmic_group_get_iohandle(slot) -- a coolmic_iohandle_t that delivers
+ *                the stream's transformed PCM in whole frames, like the handle of
+ *                coolmic_transform_get_iohandle() (ref: src/transform.c:126-193)
+ *   meter:       coolmic_group_vumeter_result(slot) -- the contract of
+ *                coolmic_vumeter_result() (ref: src/vumeter.c:189-218)
+ *
+ * coolmic_group_pump() moves one block: it pulls up to block_frames from every
+ * upstream handle into pinned staging (partial frames are carried to the next pump,
+ * as ref: src/transform.c:155-160 does per read), uploads, runs the fused
+ * channel-map/gain/VU kernel once over all streams, and downloads the PCM into the
+ * streams' output queues.  A read on an empty downstream handle pumps by itself, so
+ * a purely pull-driven chain works unchanged; streams are read ahead by at most
+ * `queue_blocks` blocks, and parameter changes take effect at the next pump.
+ */
+#ifndef __COOLMIC_DSP_GROUP_H__
+#define __COOLMIC_DSP_GROUP_H__
+
+#include <stdint.h>
+#include <sys/types.h>
+#include "ro-compat.h"
+#include "iohandle.h"
+#include "vumeter.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct coolmic_group coolmic_group_t;
+
+/* NULL for rate/channels/max_streams/block_frames of 0, channels > 16, or no usable GPU.
+ * queue_blocks >= 1 is how many processed blocks a stream may hold unread. */
+coolmic_group_t    *coolmic_group_new(const char *name, igloo_ro_t associated, uint_least32_t rate,
+                                      unsigned int channels, unsigned int max_streams,
+                                      size_t block_frames, unsigned int queue_blocks);
+
+/* adds a stream fed by `source` (takes its own reference); returns the slot (>= 0) or
+ * COOLMIC_ERROR_FAULT / COOLMIC_ERROR_BUSY when the group is full */
+int                 coolmic_group_add_stream(coolmic_group_t *self, coolmic_iohandle_t *source);
+
+/* per-stream parameters, rules of coolmic_transform_set_master_gain / _set_channel_map */
+int                 coolmic_group_set_master_gain(coolmic_group_t *self, unsigned int slot,
+                                                  unsigned int channels, uint16_t scale,
+                                                  const uint16_t *gain);
+int                 coolmic_group_set_channel_map(coolmic_group_t *self, unsigned int slot,
+                                                  const uint8_t *map);
+
+/* transformed PCM of one stream; keeps the group alive while it lives */
+coolmic_iohandle_t *coolmic_group_get_iohandle(coolmic_group_t *self, unsigned int slot);
+
+/* one block for every stream whose queue has room.  Returns the number of streams that
+ * delivered at least one frame, 0 when nothing moved, negative on error. */
+int                 coolmic_group_pump(coolmic_group_t *self);
+
+/* VU window of one stream since its last result; COOLMIC_ERROR_INVAL while it holds no frame */
+int                 coolmic_group_vumeter_result(coolmic_group_t *self, unsigned int slot,
+                                                 coolmic_vumeter_result_t *result);
+
+unsigned int        coolmic_group_streams(coolmic_group_t *self);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -139,6 +139,15 @@ SIGNATURES = {
     "coolmic_snddev_new": (_vp, [C.c_char_p, _vp, C.c_char_p, _vp, C.c_uint32, C.c_uint, C.c_int,
                                  ssize_t]),
     "coolmic_snddev_get_iohandle": (_vp, [_vp]),
+    # include/coolmic-dsp/group.h
+    "coolmic_group_new": (_vp, [C.c_char_p, _vp, C.c_uint32, C.c_uint, C.c_uint, C.c_size_t, C.c_uint]),
+    "coolmic_group_add_stream": (C.c_int, [_vp, _vp]),
+    "coolmic_group_set_master_gain": (C.c_int, [_vp, C.c_uint, C.c_uint, C.c_uint16, _P(C.c_uint16)]),
+    "coolmic_group_set_channel_map": (C.c_int, [_vp, C.c_uint, _vp]),
+    "coolmic_group_get_iohandle": (_vp, [_vp, C.c_uint]),
+    "coolmic_group_pump": (C.c_int, [_vp]),
+    "coolmic_group_vumeter_result": (C.c_int, [_vp, C.c_uint, _P(VuResult)]),
+    "coolmic_group_streams": (C.c_uint, [_vp]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)
@@ -496,6 +505,49 @@ class Vumeter:
 
     def reset(self):
         return lib.coolmic_vumeter_reset(self.ptr)
+
+    def unref(self):
+        if self.ptr:
+            lib.coolmic_ro_unref(self.ptr)
+            self.ptr = None
+
+
+class Group:
+    """coolmic_group_t: many transform -> vumeter pipelines, one launch per block"""
+
+    def __init__(self, channels, max_streams, block_frames, queue_blocks=2, rate=48000):
+        self.ptr = lib.coolmic_group_new(None, None, rate, channels, max_streams, block_frames,
+                                         queue_blocks)
+        if not self.ptr:
+            raise CoolmicError("coolmic_group_new", ERROR_GENERIC)
+        self.channels = channels
+
+    def add_stream(self, handle):
+        return lib.coolmic_group_add_stream(self.ptr, handle.ptr if handle else None)
+
+    def set_master_gain(self, slot, channels, scale, gains):
+        arr = (C.c_uint16 * len(gains))(*gains) if gains is not None and len(gains) else None
+        return lib.coolmic_group_set_master_gain(self.ptr, slot, channels, scale, arr)
+
+    def set_channel_map(self, slot, cmap):
+        if cmap is None:
+            return lib.coolmic_group_set_channel_map(self.ptr, slot, None)
+        m = np.asarray(cmap, dtype=np.uint8)
+        return lib.coolmic_group_set_channel_map(self.ptr, slot, m.ctypes.data)
+
+    def get_iohandle(self, slot):
+        return IoHandle(lib.coolmic_group_get_iohandle(self.ptr, slot))
+
+    def pump(self):
+        return lib.coolmic_group_pump(self.ptr)
+
+    def vumeter_result(self, slot):
+        r = VuResult()
+        rc = lib.coolmic_group_vumeter_result(self.ptr, slot, C.byref(r))
+        return rc, r
+
+    def streams(self):
+        return lib.coolmic_group_streams(self.ptr)
 
     def unref(self):
         if self.ptr:
