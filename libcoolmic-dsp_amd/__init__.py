@@ -139,6 +139,10 @@ SIGNATURES = {
     "coolmic_snddev_new": (_vp, [C.c_char_p, _vp, C.c_char_p, _vp, C.c_uint32, C.c_uint, C.c_int,
                                  ssize_t]),
     "coolmic_snddev_get_iohandle": (_vp, [_vp]),
+    # include/coolmic-dsp/tee.h
+    "coolmic_tee_new": (_vp, [C.c_char_p, _vp, C.c_size_t]),
+    "coolmic_tee_attach_iohandle": (C.c_int, [_vp, _vp]),
+    "coolmic_tee_get_iohandle": (_vp, [_vp, ssize_t]),
     # include/coolmic-dsp/group.h
     "coolmic_group_new": (_vp, [C.c_char_p, _vp, C.c_uint32, C.c_uint, C.c_uint, C.c_size_t, C.c_uint]),
     "coolmic_group_add_stream": (C.c_int, [_vp, _vp]),
@@ -505,6 +509,24 @@ class Vumeter:
 
     def reset(self):
         return lib.coolmic_vumeter_reset(self.ptr)
+
+    def unref(self):
+        if self.ptr:
+            lib.coolmic_ro_unref(self.ptr)
+            self.ptr = None
+
+
+class Tee:
+    def __init__(self, readers):
+        self.ptr = lib.coolmic_tee_new(None, None, readers)
+        if not self.ptr:
+            raise CoolmicError("coolmic_tee_new", ERROR_GENERIC)
+
+    def attach(self, handle):
+        return lib.coolmic_tee_attach_iohandle(self.ptr, handle.ptr if handle else None)
+
+    def get_iohandle(self, index=-1):
+        return IoHandle(lib.coolmic_tee_get_iohandle(self.ptr, index))
 
     def unref(self):
         if self.ptr:

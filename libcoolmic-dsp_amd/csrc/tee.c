@@ -1,0 +1,178 @@
+/* tee.c -- byte fan-out (contract: <coolmic-dsp/tee.h>; ref: src/tee.c). */
+#define COOLMIC_COMPONENT "libcoolmic-dsp/tee"
+#include "host_internal.h"
+#include <coolmic-dsp/tee.h>
+
+#include <stdlib.h>
+#include <string.h>
+
+#define TEE_BUFFER_MIN 1024
+#define TEE_BUFFER_MAX 8192
+
+struct coolmic_tee {
+    coolmic_ro_base_t base;
+    coolmic_iohandle_t *in;
+    size_t readers;
+    ssize_t next_reader;
+    unsigned char *buffer;
+    size_t capacity, fill;
+    size_t pos[COOLMIC_DSP_TEE_MAX_READERS];    /* read position of each reader in buffer */
+};
+
+typedef struct {
+    coolmic_tee_t *tee;
+    size_t index;
+} tee_reader_t;
+
+static void tee_destroy(void *self)
+{
+    coolmic_tee_t *t = self;
+    coolmic_ro_unref(t->in);
+    free(t->buffer);
+}
+
+static const coolmic_ro_type_t tee_type = {"coolmic_tee_t", sizeof(coolmic_tee_t), tee_destroy};
+
+coolmic_tee_t *coolmic_tee_new(const char *name, igloo_ro_t associated, size_t readers)
+{
+    coolmic_tee_t *t;
+
+    if (readers < 1 || readers > COOLMIC_DSP_TEE_MAX_READERS)
+        return NULL;
+    t = coolmic_ro_new_raw(&tee_type, name, associated);
+    if (t != NULL)
+        t->readers = readers;
+    return t;
+}
+
+int coolmic_tee_attach_iohandle(coolmic_tee_t *self, coolmic_iohandle_t *handle)
+{
+    if (self == NULL)
+        return COOLMIC_ERROR_FAULT;
+    coolmic_ro_unref(self->in);
+    self->in = handle;
+    coolmic_ro_ref(handle);
+    return COOLMIC_ERROR_NONE;
+}
+
+/* drop what every reader has seen, grow the buffer towards the request (clamped) */
+static void tee_make_room(coolmic_tee_t *t, size_t want)
+{
+    size_t low = t->fill, i;
+
+    if (want < TEE_BUFFER_MIN)
+        want = TEE_BUFFER_MIN;
+    else if (want > TEE_BUFFER_MAX)
+        want = TEE_BUFFER_MAX;
+    if (want > t->capacity) {
+        unsigned char *grown = realloc(t->buffer, want);
+        if (grown != NULL) {
+            t->buffer = grown;
+            t->capacity = want;
+        } else {
+            coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_NOMEM,
+                                "Can not allocate new buffer");
+        }
+    }
+    if (t->buffer == NULL)
+        return;
+    for (i = 0; i < t->readers; i++)
+        if (t->pos[i] < low)
+            low = t->pos[i];
+    if (low > 0) {
+        memmove(t->buffer, t->buffer + low, t->fill - low);
+        t->fill -= low;
+        for (i = 0; i < t->readers; i++)
+            t->pos[i] -= low;
+    }
+}
+
+/* one upstream read into the free part of the buffer; <1 when nothing came */
+static ssize_t tee_pull(coolmic_tee_t *t, size_t want)
+{
+    size_t room;
+    ssize_t got;
+
+    tee_make_room(t, want);
+    room = t->capacity - t->fill;
+    if (t->buffer == NULL || room == 0) {
+        coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_NOMEM,
+                            "Physical read failed, buffer=%p, room=%zu", (void *)t->buffer, room);
+        return -1;
+    }
+    if (room > want)
+        room = want;
+    got = coolmic_iohandle_read(t->in, t->buffer + t->fill, room);
+    if (got < 1)
+        return got;
+    t->fill += (size_t)got;
+    return got;
+}
+
+static ssize_t tee_reader_read(void *userdata, void *buffer, size_t len)
+{
+    tee_reader_t *r = userdata;
+    coolmic_tee_t *t = r->tee;
+    unsigned char *dst = buffer;
+    size_t done = 0;
+
+    while (len) {
+        size_t have = t->fill - t->pos[r->index];
+        if (have == 0) {
+            if (tee_pull(t, len) < 1)
+                break;
+            have = t->fill - t->pos[r->index];
+            if (have == 0)
+                break;
+        }
+        if (have > len)
+            have = len;
+        memcpy(dst, t->buffer + t->pos[r->index], have);
+        t->pos[r->index] += have;
+        dst += have;
+        done += have;
+        len -= have;
+    }
+    return (ssize_t)done;
+}
+
+static int tee_reader_eof(void *userdata)
+{
+    tee_reader_t *r = userdata;
+    if (r->tee->pos[r->index] < r->tee->fill)
+        return 0;
+    return coolmic_iohandle_eof(r->tee->in);
+}
+
+static int tee_reader_free(void *userdata)
+{
+    tee_reader_t *r = userdata;
+    coolmic_ro_unref(r->tee);
+    free(r);
+    return 0;
+}
+
+coolmic_iohandle_t *coolmic_tee_get_iohandle(coolmic_tee_t *self, ssize_t index)
+{
+    tee_reader_t *r;
+    coolmic_iohandle_t *h;
+
+    if (self == NULL)
+        return NULL;
+    if (index == -1)
+        index = self->next_reader;
+    if (index < 0 || (size_t)index >= self->readers)
+        return NULL;               /* the reference checks against 4, not the reader count */
+    self->next_reader = index + 1;
+
+    r = calloc(1, sizeof(*r));
+    if (r == NULL)
+        return NULL;
+    coolmic_ro_ref(self);
+    r->tee = self;
+    r->index = (size_t)index;
+    h = coolmic_iohandle_new(NULL, igloo_RO_NULL, r, tee_reader_free, tee_reader_read, tee_reader_eof);
+    if (h == NULL)
+        tee_reader_free(r);
+    return h;
+}

@@ -15,6 +15,7 @@ HEADERS = [
     "include/coolmic-dsp/transform.h",
     "include/coolmic-dsp/vumeter.h",
     "include/coolmic-dsp/snddev.h",
+    "include/coolmic-dsp/tee.h",
     "include/coolmic-dsp/group.h",
 ]
 DECL = re.compile(r"\b((?:cmhip|coolmic)_[a-z0-9_]+)\s*\(")

@@ -129,3 +129,43 @@ def test_chain_matches_oracle_on_noise_with_map(gpu, oracle):
     assert rc == 0 and r.as_dict() == of.vu_result_dict(ro)
     for o in (h, vu, tr):
         o.unref()
+
+
+def test_product_wiring_with_tee(gpu, oracle):
+    """snddev -> transform -> tee -> {encoder branch, vumeter}, as ref: src/simple.c:183-236
+    wires it; the encoder branch is played by a reader pulling 1024 bytes at a time
+    (ref: src/enc_vorbis.c:91)."""
+    cm = gpu
+    C, frames = 2, 30000
+    x = oracle.lcg(77, frames * C)
+    src = cm.IoHandle.from_bytes(x.tobytes(), chunk=4096)
+    tr = cm.Transform(48000, C)
+    assert tr.attach(src) == 0
+    src.unref()
+    assert tr.set_master_gain(2, 1000, [750, 1250]) == 0
+    tee = cm.Tee(2)
+    h = tr.get_iohandle()
+    assert tee.attach(h) == 0
+    h.unref()
+    enc_in = tee.get_iohandle(0)
+    vu = cm.Vumeter(48000, C)
+    h = tee.get_iohandle(1)
+    assert vu.attach(h) == 0
+    h.unref()
+    pcm = b""
+    for _ in range(100000):
+        n, d = enc_in.read(1024)
+        pcm += d
+        m = vu.read(-1)
+        if n == 0 and m <= 0 and enc_in.eof() == 1:
+            break
+    _, g = oracle.gain(C, 2, 1000, [750, 1250])
+    want = oracle.gain_apply(g, x, C)
+    assert np.array_equal(np.frombuffer(pcm, np.int16), want)
+    rc, r = vu.result()
+    v = oracle.vu_new(C)
+    oracle.vu_accumulate(v, want)
+    _, ro = oracle.vu_result(v)
+    assert rc == 0 and r.as_dict() == of.vu_result_dict(ro)
+    for o in (enc_in, vu, tee, tr):
+        o.unref()

@@ -256,3 +256,50 @@ def test_logging_format(cm):
     assert "libcoolmic-dsp/transform in " in logs[0][1] and "DEBUG: gain: scale=7, gain[0]=3 (in: 3, 4)" in logs[0][1]
     assert cm.lib.coolmic_logging_level2string(1) == b"ERROR"
     assert cm.lib.coolmic_logging_level2string(99) == b"(unknown)"
+
+
+def test_tee_fanout(cm):
+    # ref: src/tee.c:83-289
+    assert not cm.lib.coolmic_tee_new(None, None, 0)
+    assert not cm.lib.coolmic_tee_new(None, None, 5)
+    data = bytes(range(256)) * 40                      # 10240 bytes
+    tee = cm.Tee(2)
+    src = cm.IoHandle.from_bytes(data, chunk=700)
+    assert tee.attach(src) == 0
+    src.unref()
+    a = tee.get_iohandle(-1)
+    b = tee.get_iohandle(-1)
+    assert not cm.lib.coolmic_tee_get_iohandle(tee.ptr, -1)       # only two readers
+    assert not cm.lib.coolmic_tee_get_iohandle(tee.ptr, 2)
+    got_a, got_b = b"", b""
+    # reader a runs ahead until the shared buffer (<= 8192 bytes) is full, then starves
+    while True:
+        n, d = a.read(1024)
+        got_a += d
+        if n == 0:
+            break
+    assert 1024 <= len(got_a) <= 8192 and a.eof() == 0
+    n, d = b.read(300)
+    got_b += d
+    assert n == 300
+    n, d = a.read(1024)                                # room again after b moved on
+    got_a += d
+    assert n > 0
+    for h, got in ((a, got_a), (b, got_b)):
+        pass
+    # drain both alternately
+    for _ in range(200):
+        n, d = b.read(1000); got_b += d
+        n2, d2 = a.read(1000); got_a += d2
+        if n == 0 and n2 == 0 and a.eof() == 1 and b.eof() == 1:
+            break
+    assert got_a == data and got_b == data
+    a.unref(); b.unref(); tee.unref()
+
+
+def test_group_needs_a_gpu(cm):
+    if cm.device_count() > 0:
+        pytest.skip("a GPU is present")
+    assert not cm.lib.coolmic_group_new(None, None, 48000, 2, 4, 512, 2)
+    assert not cm.lib.coolmic_group_new(None, None, 0, 2, 4, 512, 2)
+    assert cm.lib.coolmic_group_pump(None) == cm.ERROR_FAULT
