@@ -75,11 +75,20 @@ def main():
 
     if cm.device_count() < 1:
         sys.exit("bench.py: no HIP device; this path has no CPU fallback")
+    # Rehearsal knobs for a 1-GPU box (never set by the driver): all ranks share one device
+    # and the process group runs over gloo, so the N>1 code path can be exercised without N GPUs.
+    rehearsal = os.environ.get("COOLMIC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+    coll_device = "cpu" if rehearsal else "cuda"
 
     S, Cn, T, bps, desc = WORKLOADS[args.workload]
     if args.frames:
@@ -111,6 +120,7 @@ def main():
     results = (cm.VuResult * S)()
     rcs = (C.c_int * S)()
     node_words = torch.zeros(cm.NODE_WORDS, dtype=torch.int64, device="cuda") if node_vu else None
+    node_host = torch.zeros(cm.NODE_WORDS, dtype=torch.int64) if node_vu and rehearsal else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -125,7 +135,11 @@ def main():
             if node_vu and world > 1:
                 b.node_partial(node_words.data_ptr(), first_global=rank, global_step=world)
                 b.sync()      # the record is produced on the batch's stream, RCCL uses torch's
-                shard.combine_node_records(dist, node_words)
+                if rehearsal:                 # gloo: combine on the host copy
+                    node_host.copy_(node_words)
+                    shard.combine_node_records(dist, node_host)
+                else:
+                    shard.combine_node_records(dist, node_words)
             if has_vu:
                 if pending:
                     b.vu_collect(results, rcs)       # dB finish of the previous window (host)
@@ -147,7 +161,7 @@ def main():
     b.timing(False)
 
     if world > 1:
-        dt = shard.max_over_ranks(dist, dt, device="cuda")
+        dt = shard.max_over_ranks(dist, dt, device=coll_device)
 
     samples_per_step_rank = S * Cn * T
     total_samples = samples_per_step_rank * world * args.steps
