@@ -698,24 +698,31 @@ __device__ __forceinline__ float biquad_step(float x0, float &x1, float &x2, flo
     return y;
 }
 
-// G = streams per workgroup (8, 16 or 32): one loader wave per 8 streams.  Small groups
-// mean several independent pipelines per CU, which hides the barrier and LDS latencies of
-// each other; the section waves then run with G of 64 lanes doing distinct work.
+// G = streams per workgroup (8, 16 or 32): one loader wave per 8 streams.  A section wave
+// carries 64/G sections side by side in its lanes (lane = section * G + stream): the same
+// instruction stream runs every section of the cascade, each lane group one block behind
+// the previous one, so the scarce resource -- issue slots of the recurrence -- is spent on
+// 64 useful lanes.  With G = 16 one wave runs up to four sections of 16 streams and a
+// workgroup is just 2 loaders + 1 section wave + 1 store wave, small enough for several
+// independent pipelines per CU to hide each other's barrier and LDS latencies.
 template <int NSEC, int G>
-__global__ __launch_bounds__((NSEC + 1 + G / 8) * 64) void k_eq_pipe(EqArgs a)
+__global__ __launch_bounds__(((NSEC + 64 / G - 1) / (64 / G) + 1 + G / 8) * 64) void k_eq_pipe(EqArgs a)
 {
     constexpr u32 EP_G = G;
     constexpr u32 EP_TILE = EP_G * EP_ROW;   // floats per buffer slot
+    constexpr u32 SPW = 64 / G;              // sections per section wave
+    constexpr u32 NSW = (NSEC + SPW - 1) / SPW;   // section waves
     extern __shared__ float lds[];       // (NSEC+1) buffers x 2 slots x EP_TILE floats, then G counts
     u32 *nfr_lds = reinterpret_cast<u32 *>(lds + (NSEC + 1) * 2 * EP_TILE);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const u32 s0 = blockIdx.x * EP_G;
 
     // roles by wave index (see the SIMD pairing note above)
-    const bool is_section = wave < (u32)NSEC;
-    const bool is_loader = wave > (u32)NSEC;
-    const u32 lw = wave - (u32)NSEC - 1u;                 // loader index 0..G/8-1
-    const u32 sec = wave;                                 // section index for section waves
+    const bool is_section = wave < NSW;
+    const bool is_loader = wave > NSW;
+    const u32 lw = wave - NSW - 1u;                       // loader index 0..G/8-1
+    const u32 sec = wave * SPW + lane / EP_G;             // section of this lane (section waves)
+    const bool has_sec = is_section && sec < (u32)NSEC;
 
     // frame counts of the G streams; lanes beyond G mirror the first G
     const u32 row = lane % EP_G;
@@ -745,7 +752,7 @@ __global__ __launch_bounds__((NSEC + 1 + G / 8) * 64) void k_eq_pipe(EqArgs a)
     }
     // sections: coefficients and state of this lane's stream
     float b0 = 0, b1 = 0, b2 = 0, na1 = 0, na2 = 0, x1 = 0, x2 = 0, y1 = 0, y2 = 0;
-    if (is_section && live) {
+    if (has_sec && live) {
         const float *c = a.eq[sl].coef[sec];
         b0 = c[0]; b1 = c[1]; b2 = c[2]; na1 = -c[3]; na2 = -c[4];
         const float *st = a.state[sl].s[sec];
@@ -798,8 +805,10 @@ __global__ __launch_bounds__((NSEC + 1 + G / 8) * 64) void k_eq_pipe(EqArgs a)
                 dstx[1] = make_float4(f[4], f[5], f[6], f[7]);
             }
         } else if (is_section) {
+            // every lane group runs the same code on its own section, one block apart
             const u32 stage = sec + 1u;
-            if (step >= stage && step - stage < nblocks) {
+            const bool act = has_sec && step >= stage && step - stage < nblocks;
+            if (act) {
                 const u32 b = step - stage;
                 const float *in = lds + (sec * 2u + (b & 1u)) * EP_TILE + row * EP_ROW;
                 float *out = lds + ((sec + 1u) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW;
@@ -860,7 +869,7 @@ __global__ __launch_bounds__((NSEC + 1 + G / 8) * 64) void k_eq_pipe(EqArgs a)
         __syncthreads();
     }
 
-    if (is_section && live && lane < EP_G) {
+    if (has_sec && live) {
         float *st = a.state[sl].s[sec];
         st[0] = x1; st[1] = x2; st[2] = y1; st[3] = y2;
     }
@@ -878,7 +887,8 @@ static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
             return e;
         configured = true;
     }
-    hipLaunchKernelGGL((k_eq_pipe<NSEC, G>), dim3((a.streams + G - 1) / G), dim3((NSEC + 1 + G / 8) * 64),
+    constexpr int SPW = 64 / G, NSW = (NSEC + SPW - 1) / SPW;
+    hipLaunchKernelGGL((k_eq_pipe<NSEC, G>), dim3((a.streams + G - 1) / G), dim3((NSW + 1 + G / 8) * 64),
                        lds_bytes, st, a);
     return hipGetLastError();
 }
