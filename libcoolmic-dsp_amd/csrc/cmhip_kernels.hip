@@ -667,64 +667,58 @@ __global__ __launch_bounds__(64) void k_eq(EqArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// Pipelined EQ (float output only, 1..3 sections): the fast form of config 3.
+// Pipelined EQ (float output only, 1..4 sections): the fast form of config 3.
 //
-// The recurrence allows no parallelism along time and a lane per stream gives only
-// streams/64 waves, so the per-sample work is spread over the waves of a workgroup as a
-// pipeline: four loader waves (global load, gain, int16 -> float), one wave per biquad
-// section (lane = stream; operands and results through LDS as b128), one store wave.
-// Each inter-stage buffer holds a 32-stream x 64-frame tile twice; stage k works on
-// block step-k, one __syncthreads() per step.
+// The recurrence allows no parallelism along time, and what limits a wave that walks a
+// stream is its own issue rate (one VALU op per ~4-5 cycles when it is the only ready wave
+// of its SIMD).  So the per-sample work is cut into pipeline stages that run in different
+// waves of a workgroup, connected by double-buffered LDS tiles, one __syncthreads() per
+// 64-frame block:
 //
-// Sizing, from stage ablation on MI355X: a CU moves ~10 B/clk of global traffic, so a
-// workgroup takes 32 streams (12 KiB per step) and config 3 spreads over all 256 CUs;
-// a section wave needs ~350 issue slots per block and must not share its SIMD with
-// another heavy wave, so the roles are ordered section,section,section,store,loader x4:
-// waves i and i+4 land on the same SIMD, pairing each section wave with one light loader.
-// Rows are 68 floats: 16-byte aligned and conflict-free for lane-per-row b128 access.
+//   loaders  global load (next block prefetched), gain, int16 -> float        -> X
+//   FIR_k    f[t] = fma(b2, x[t-2], fma(b1, x[t-1], b0*x[t]))   (3 ops/sample)  -> F_k
+//   REC_k    y[t] = fma(-a1, y[t-1], fma(-a2, y[t-2], f[t]))    (2 ops/sample)  -> Y_k
+//   store    coalesced non-temporal stores of Y_last
+//
+// This is the oracle's Direct Form I evaluated in the same order, only cut in two: the
+// feed-forward half has no loop-carried dependence, the recurrence keeps just the two
+// dependent FMAs.  A FIR wave and a REC wave each carry 64/G sections side by side in
+// their lanes (lane = section * G + stream), every lane group one stage behind the
+// previous one, so one instruction stream serves the whole cascade.  Rows are 68 floats:
+// 16-byte aligned and conflict-free for lane-per-row b128 access, also across lane groups
+// (tile sizes are multiples of 64 floats).
+//
+// Sizing notes from stage ablation on MI355X: a CU moves ~10 B/clk of global traffic, so a
+// workgroup takes 16 streams (6 KiB per step) and two workgroups share a CU; the waves are
+// ordered REC, FIR, store, loaders so that the recurrence waves land on their own SIMDs.
 
 constexpr u32 EP_TB = 64;                // frames per block
 constexpr u32 EP_ROW = 68;               // floats per LDS row
 
-__device__ __forceinline__ float biquad_step(float x0, float &x1, float &x2, float &y1, float &y2,
-                                             float b0, float b1, float b2, float na1, float na2)
-{
-    const float f = __builtin_fmaf(b2, x2, __builtin_fmaf(b1, x1, b0 * x0));
-    const float y = __builtin_fmaf(na1, y1, __builtin_fmaf(na2, y2, f));
-    x2 = x1;
-    x1 = x0;
-    y2 = y1;
-    y1 = y;
-    return y;
-}
-
-// G = streams per workgroup (8, 16 or 32): one loader wave per 8 streams.  A section wave
-// carries 64/G sections side by side in its lanes (lane = section * G + stream): the same
-// instruction stream runs every section of the cascade, each lane group one block behind
-// the previous one, so the scarce resource -- issue slots of the recurrence -- is spent on
-// 64 useful lanes.  With G = 16 one wave runs up to four sections of 16 streams and a
-// workgroup is just 2 loaders + 1 section wave + 1 store wave, small enough for several
-// independent pipelines per CU to hide each other's barrier and LDS latencies.
 template <int NSEC, int G>
-__global__ __launch_bounds__(((NSEC + 64 / G - 1) / (64 / G) + 1 + G / 8) * 64) void k_eq_pipe(EqArgs a)
+__global__ __launch_bounds__((2 * ((NSEC + 64 / G - 1) / (64 / G)) + 1 + G / 8) * 64)
+void k_eq_pipe(EqArgs a)
 {
     constexpr u32 EP_G = G;
-    constexpr u32 EP_TILE = EP_G * EP_ROW;   // floats per buffer slot
-    constexpr u32 SPW = 64 / G;              // sections per section wave
-    constexpr u32 NSW = (NSEC + SPW - 1) / SPW;   // section waves
-    extern __shared__ float lds[];       // (NSEC+1) buffers x 2 slots x EP_TILE floats, then G counts
-    u32 *nfr_lds = reinterpret_cast<u32 *>(lds + (NSEC + 1) * 2 * EP_TILE);
+    constexpr u32 EP_TILE = EP_G * EP_ROW;        // floats per buffer slot
+    constexpr u32 SPW = 64 / G;                   // sections per FIR / REC wave
+    constexpr u32 NSW = (NSEC + SPW - 1) / SPW;   // FIR waves = REC waves
+    constexpr u32 NBUF = 2 * NSEC + 1;            // X, F_0, Y_0, F_1, Y_1, ...
+    extern __shared__ float lds[];                // NBUF buffers x 2 slots x EP_TILE floats, then G counts
+    u32 *nfr_lds = reinterpret_cast<u32 *>(lds + NBUF * 2 * EP_TILE);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const u32 s0 = blockIdx.x * EP_G;
 
-    // roles by wave index (see the SIMD pairing note above)
-    const bool is_section = wave < NSW;
-    const bool is_loader = wave > NSW;
-    const u32 lw = wave - NSW - 1u;                       // loader index 0..G/8-1
-    const u32 sec = wave * SPW + lane / EP_G;             // section of this lane (section waves)
-    const bool has_sec = is_section && sec < (u32)NSEC;
+    // roles by wave index
+    const bool is_rec = wave < NSW;
+    const bool is_fir = wave >= NSW && wave < 2 * NSW;
+    const bool is_store = wave == 2 * NSW;
+    const bool is_loader = wave > 2 * NSW;
+    const u32 lw = wave - 2 * NSW - 1u;                   // loader index 0..G/8-1
+    const u32 sec = (is_rec ? wave : wave - NSW) * SPW + lane / EP_G;   // section of this lane
+    const bool has_sec = (is_rec || is_fir) && sec < (u32)NSEC;
 
-    // frame counts of the G streams; lanes beyond G mirror the first G
+    // frame counts of the G streams; lane groups beyond the first mirror it
     const u32 row = lane % EP_G;
     const u32 sl = s0 + row;
     const bool live = sl < a.streams;
@@ -736,7 +730,7 @@ __global__ __launch_bounds__(((NSEC + 64 / G - 1) / (64 / G) + 1 + G / 8) * 64) 
     for (int o = G / 2; o > 0; o >>= 1)
         nmax = max(nmax, (u32)__shfl_xor((int)nmax, o, 64));
     const u32 nblocks = (nmax + EP_TB - 1) / EP_TB;
-    const u32 nsteps = nblocks + NSEC + 1;
+    const u32 nsteps = nblocks + 2 * NSEC + 1;
     __syncthreads();
 
     // loaders: lane handles stream r = 8*lw + lane/8, frames (lane%8)*8 .. +7 of each block
@@ -750,13 +744,18 @@ __global__ __launch_bounds__(((NSEC + 64 / G - 1) / (64 / G) + 1 + G / 8) * 64) 
         l_g2 = a.param[sr].gain2[0];
         l_n = nfr_lds[l_r];
     }
-    // sections: coefficients and state of this lane's stream
-    float b0 = 0, b1 = 0, b2 = 0, na1 = 0, na2 = 0, x1 = 0, x2 = 0, y1 = 0, y2 = 0;
+    // FIR lanes own x1,x2 of their section, REC lanes own y1,y2 (EqState: x1 x2 y1 y2)
+    float c0 = 0, c1 = 0, c2 = 0, h1 = 0, h2 = 0;
     if (has_sec && live) {
         const float *c = a.eq[sl].coef[sec];
-        b0 = c[0]; b1 = c[1]; b2 = c[2]; na1 = -c[3]; na2 = -c[4];
         const float *st = a.state[sl].s[sec];
-        x1 = st[0]; x2 = st[1]; y1 = st[2]; y2 = st[3];
+        if (is_fir) {
+            c0 = c[0]; c1 = c[1]; c2 = c[2];
+            h1 = st[0]; h2 = st[1];
+        } else {
+            c1 = -c[3]; c2 = -c[4];
+            h1 = st[2]; h2 = st[3];
+        }
     }
 
     // loaders keep the NEXT block's PCM in flight while the pipeline works on this one:
@@ -804,48 +803,69 @@ __global__ __launch_bounds__(((NSEC + 64 / G - 1) / (64 / G) + 1 + G / 8) * 64) 
                 dstx[0] = make_float4(f[0], f[1], f[2], f[3]);
                 dstx[1] = make_float4(f[4], f[5], f[6], f[7]);
             }
-        } else if (is_section) {
-            // every lane group runs the same code on its own section, one block apart
-            const u32 stage = sec + 1u;
+        } else if (is_rec || is_fir) {
+            // every lane group runs the same code on its own section, one stage apart
+            const u32 inbuf = 2u * sec + (is_rec ? 1u : 0u);
+            const u32 stage = inbuf + 1u;
             const bool act = has_sec && step >= stage && step - stage < nblocks;
             if (act) {
                 const u32 b = step - stage;
-                const float *in = lds + (sec * 2u + (b & 1u)) * EP_TILE + row * EP_ROW;
-                float *out = lds + ((sec + 1u) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW;
+                const float *in = lds + (inbuf * 2u + (b & 1u)) * EP_TILE + row * EP_ROW;
+                float *out = lds + ((inbuf + 1u) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW;
                 const u32 done = b * EP_TB;
                 const u32 cnt = my_nfr > done ? min(my_nfr - done, EP_TB) : 0u;
                 if (__all(cnt == EP_TB)) {
-                    // whole row into registers first: 16 LDS reads in flight at once instead
-                    // of one exposed LDS latency per four samples
+                    // whole row into registers first: 16 LDS reads in flight at once
                     float4 v[EP_TB / 4];
 #pragma unroll
                     for (u32 t = 0; t < EP_TB / 4; t++)
                         v[t] = reinterpret_cast<const float4 *>(in)[t];
+                    if (is_fir) {
 #pragma unroll
-                    for (u32 t = 0; t < EP_TB / 4; t++) {
-                        float4 y;
-                        y.x = biquad_step(v[t].x, x1, x2, y1, y2, b0, b1, b2, na1, na2);
-                        y.y = biquad_step(v[t].y, x1, x2, y1, y2, b0, b1, b2, na1, na2);
-                        y.z = biquad_step(v[t].z, x1, x2, y1, y2, b0, b1, b2, na1, na2);
-                        y.w = biquad_step(v[t].w, x1, x2, y1, y2, b0, b1, b2, na1, na2);
-                        reinterpret_cast<float4 *>(out)[t] = y;
+                        for (u32 t = 0; t < EP_TB / 4; t++) {
+                            float4 f;
+                            f.x = __builtin_fmaf(c2, h2, __builtin_fmaf(c1, h1, c0 * v[t].x));
+                            f.y = __builtin_fmaf(c2, h1, __builtin_fmaf(c1, v[t].x, c0 * v[t].y));
+                            f.z = __builtin_fmaf(c2, v[t].x, __builtin_fmaf(c1, v[t].y, c0 * v[t].z));
+                            f.w = __builtin_fmaf(c2, v[t].y, __builtin_fmaf(c1, v[t].z, c0 * v[t].w));
+                            h2 = v[t].z;
+                            h1 = v[t].w;
+                            reinterpret_cast<float4 *>(out)[t] = f;
+                        }
+                    } else {
+#pragma unroll
+                        for (u32 t = 0; t < EP_TB / 4; t++) {
+                            float4 y;
+                            y.x = __builtin_fmaf(c1, h1, __builtin_fmaf(c2, h2, v[t].x));
+                            y.y = __builtin_fmaf(c1, y.x, __builtin_fmaf(c2, h1, v[t].y));
+                            y.z = __builtin_fmaf(c1, y.y, __builtin_fmaf(c2, y.x, v[t].z));
+                            y.w = __builtin_fmaf(c1, y.z, __builtin_fmaf(c2, y.y, v[t].w));
+                            h2 = y.z;
+                            h1 = y.w;
+                            reinterpret_cast<float4 *>(out)[t] = y;
+                        }
                     }
                 } else {                                 // some stream ends inside this block
                     for (u32 t = 0; t < EP_TB; t++) {
-                        float tx1 = x1, tx2 = x2, ty1 = y1, ty2 = y2;
-                        const float y = biquad_step(in[t], tx1, tx2, ty1, ty2, b0, b1, b2, na1, na2);
-                        if (t < cnt) {
-                            x1 = tx1; x2 = tx2; y1 = ty1; y2 = ty2;
+                        const float x0 = in[t];
+                        float r;
+                        if (is_fir)
+                            r = __builtin_fmaf(c2, h2, __builtin_fmaf(c1, h1, c0 * x0));
+                        else
+                            r = __builtin_fmaf(c1, h1, __builtin_fmaf(c2, h2, x0));
+                        if (t < cnt) {                   // history moves only on real samples
+                            h2 = h1;
+                            h1 = is_fir ? x0 : r;
                         }
-                        out[t] = y;
+                        out[t] = r;
                     }
                 }
             }
         } else {
-            const u32 stage = NSEC + 1;
+            const u32 stage = 2 * NSEC + 1;
             if (step >= stage && step - stage < nblocks) {
                 const u32 b = step - stage;
-                const float *Y = lds + ((u32)NSEC * 2u + (b & 1u)) * EP_TILE;
+                const float *Y = lds + ((u32)(2 * NSEC) * 2u + (b & 1u)) * EP_TILE;
 #pragma unroll
                 for (u32 i = 0; i < EP_G / 4; i++) {
                     const u32 r = 4u * i + (lane >> 4);
@@ -871,14 +891,19 @@ __global__ __launch_bounds__(((NSEC + 64 / G - 1) / (64 / G) + 1 + G / 8) * 64) 
 
     if (has_sec && live) {
         float *st = a.state[sl].s[sec];
-        st[0] = x1; st[1] = x2; st[2] = y1; st[3] = y2;
+        if (is_fir) {
+            st[0] = h1; st[1] = h2;
+        } else {
+            st[2] = h1; st[3] = h2;
+        }
     }
+    (void)is_store;
 }
 
 template <int NSEC, int G>
 static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
 {
-    const size_t lds_bytes = ((size_t)(NSEC + 1) * 2 * G * EP_ROW) * sizeof(float) + G * sizeof(u32);
+    const size_t lds_bytes = ((size_t)(2 * NSEC + 1) * 2 * G * EP_ROW) * sizeof(float) + G * sizeof(u32);
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G>),
@@ -888,7 +913,7 @@ static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
         configured = true;
     }
     constexpr int SPW = 64 / G, NSW = (NSEC + SPW - 1) / SPW;
-    hipLaunchKernelGGL((k_eq_pipe<NSEC, G>), dim3((a.streams + G - 1) / G), dim3((NSW + 1 + G / 8) * 64),
+    hipLaunchKernelGGL((k_eq_pipe<NSEC, G>), dim3((a.streams + G - 1) / G), dim3((2 * NSW + 1 + G / 8) * 64),
                        lds_bytes, st, a);
     return hipGetLastError();
 }
@@ -897,7 +922,7 @@ template <int NSEC>
 static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st)
 {
     const char *e = getenv("CMHIP_EQ_G");                 // tuning knob
-    const int g = e ? atoi(e) : 32;                       // 32: best on MI355X
+    const int g = e ? atoi(e) : 16;                       // 16: best on MI355X
     if (g == 32)
         return launch_eq_pipe<NSEC, 32>(a, st);
     if (g == 16)
@@ -910,13 +935,14 @@ hipError_t launch_eq(const EqArgs &a, hipStream_t st)
     const dim3 grid((a.streams + 63) / 64), block(64);
     if (a.streams == 0 || a.frames == 0)
         return hipSuccess;
-    // float output only, 1..3 sections: the pipelined kernel; everything else (int16
-    // result, VU of it, bypass, 4 sections) takes the one-wave-per-tile kernel below
+    // float output only, 1..4 sections: the pipelined kernel; everything else (int16
+    // result, VU of it, bypass) takes the one-wave-per-tile kernel below
     if (a.f32 && !a.out && !a.vu) {
         switch (a.nsec) {
         case 1: return launch_eq_pipe_g<1>(a, st);
         case 2: return launch_eq_pipe_g<2>(a, st);
         case 3: return launch_eq_pipe_g<3>(a, st);
+        case 4: return launch_eq_pipe_g<4>(a, st);
         default: break;
         }
     }

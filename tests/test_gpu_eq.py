@@ -99,14 +99,14 @@ def test_eq_config3_shape_sampled(gpu, oracle):
     b.close()
 
 
-@pytest.mark.parametrize("nsec", [1, 2, 3])
+@pytest.mark.parametrize("nsec", [1, 2, 3, 4])
 def test_eq_pipelined_kernel_ragged_and_state_carry(gpu, oracle, nsec):
     """float-only batches take the pipelined kernel (k_eq_pipe): ragged stream ends inside
     and across 64-frame blocks, streams of length 0, three launches with carried state"""
     cm = gpu
     rng = np.random.default_rng(100 + nsec)
     S, T = 130, 333                      # 3 workgroups (64 + 64 + 2 streams), 6 blocks
-    coef = cm.eq3(48000.0)[: 5 * nsec]
+    coef = np.concatenate([cm.eq3(48000.0), cm.design_biquad(1, 48000.0, 3000.0, 4.0, 2.0)])[: 5 * nsec]
     b = cm.Batch(S, 1, T, flags=cm.EQ | cm.OUT_F32)
     assert b.set_eq(-1, coef) == 0
     gains = []
