@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcoolmic-dsp-hip.so")
+LIB_PATH = os.environ.get("COOLMIC_HIP_LIB") or os.path.join(_HERE, "lib", "libcoolmic-dsp-hip.so")
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: build it with `make -C {_HERE}` "

@@ -161,6 +161,7 @@ struct cmhip_batch {
     EqParam *d_eq;
     EqState *d_eqstate;
     unsigned long long *d_sink;
+    unsigned long long *d_dbg;             // 64 words, written only by diagnostic builds
 
     std::vector<StreamParam> h_param;
     std::vector<uint16_t> h_scale;         // the reference's master_gain_scale per stream
@@ -266,6 +267,7 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     (void)hipFree(b->d_eq);
     (void)hipFree(b->d_eqstate);
     (void)hipFree(b->d_sink);
+    (void)hipFree(b->d_dbg);
     if (b->h_snap)
         (void)hipHostFree(b->h_snap);
     if (b->h_stage)
@@ -319,6 +321,8 @@ static int batch_init(cmhip_batch_t *b)
     HIP_TRY(hipMalloc((void **)&b->d_nframes, S * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&b->d_sink, sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(b->d_sink, 0, sizeof(unsigned long long), b->stream));
+    HIP_TRY(hipMalloc((void **)&b->d_dbg, 64 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(b->d_dbg, 0, 64 * sizeof(unsigned long long), b->stream));
     if (d.flags & CMHIP_EQ) {
         HIP_TRY(hipMalloc((void **)&b->d_eq, S * sizeof(EqParam)));
         HIP_TRY(hipMalloc((void **)&b->d_eqstate, S * sizeof(EqState)));
@@ -391,6 +395,7 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->d_eq = nullptr;
     b->d_eqstate = nullptr;
     b->d_sink = nullptr;
+    b->d_dbg = nullptr;
     b->h_snap = nullptr;
     b->h_stage = nullptr;
     for (unsigned i = 0; i < STAGE_SLOTS; i++) {
@@ -411,6 +416,17 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
         return nullptr;
     }
     return b;
+}
+
+// diagnostic hook: the 64 stamp words a -DCMHIP_EQ_STAMPS build of the kernels writes
+extern "C" int cmhip_debug_read(cmhip_batch_t *b, unsigned long long *out)
+{
+    if (!b || !out)
+        return COOLMIC_ERROR_FAULT;
+    if (hipSetDevice(b->d.device) != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess ||
+        hipMemcpy(out, b->d_dbg, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+        return COOLMIC_ERROR_GENERIC;
+    return COOLMIC_ERROR_NONE;
 }
 
 // test hook: the division constants for a scale (host logic, needs no GPU)
@@ -763,6 +779,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.streams = b->d.streams;
         a.nsec = b->nsec;
         a.parity = b->parity;
+        a.dbg = b->d_dbg;
         a.stride = b->stride;
         a.plane = b->plane;
         HIP_TRY(launch_eq(a, b->stream));

@@ -83,6 +83,7 @@ struct EqArgs {
     uint32_t       parity;
     uint64_t       stride;
     uint64_t       plane;
+    unsigned long long *dbg;       // 64 words for in-kernel stamps (diagnostic builds only)
 };
 
 struct GenArgs {

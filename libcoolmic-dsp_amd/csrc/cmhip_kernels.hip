@@ -772,7 +772,14 @@ void k_eq_pipe(EqArgs a)
     if (is_loader && nblocks)
         fetch(0);
 
+#ifdef CMHIP_EQ_STAMPS
+    u64 st_busy = 0;
+    const u64 st_begin = __builtin_readcyclecounter();
+#endif
     for (u32 step = 0; step < nsteps; step++) {
+#ifdef CMHIP_EQ_STAMPS
+        const u64 st_t0 = __builtin_readcyclecounter();
+#endif
         if (is_loader) {
             const u32 b = step;
             if (b < nblocks) {
@@ -886,8 +893,19 @@ void k_eq_pipe(EqArgs a)
                 }
             }
         }
+#ifdef CMHIP_EQ_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        st_busy += __builtin_readcyclecounter() - st_t0;
+#endif
         __syncthreads();
     }
+#ifdef CMHIP_EQ_STAMPS
+    if (blockIdx.x == 7 && lane == 0 && a.dbg) {     // per-role busy cycles (tools/eq_stamps.py)
+        a.dbg[2 * wave] = st_busy;
+        a.dbg[2 * wave + 1] = __builtin_readcyclecounter() - st_begin;
+        a.dbg[40] = nsteps;
+    }
+#endif
 
     if (has_sec && live) {
         float *st = a.state[sl].s[sec];
@@ -922,7 +940,10 @@ template <int NSEC>
 static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st)
 {
     const char *e = getenv("CMHIP_EQ_G");                 // tuning knob
-    const int g = e ? atoi(e) : 16;                       // 16: best on MI355X
+    int g = e ? atoi(e) : 32;                             // 32: best on MI355X
+    // the tiles of a 32-stream workgroup must fit the 160 KiB of LDS
+    if (g == 32 && ((size_t)(2 * NSEC + 1) * 2 * 32 * EP_ROW) * sizeof(float) + 32 * sizeof(u32) > 160 * 1024)
+        g = 16;
     if (g == 32)
         return launch_eq_pipe<NSEC, 32>(a, st);
     if (g == 16)

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Per-role busy cycles of the pipelined EQ kernel (diagnostic build, `make stamps`).
+Run with COOLMIC_HIP_LIB=libcoolmic-dsp_amd/lib/libcoolmic-dsp-hip-stamps.so."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+
+cm = ge.load_package()
+S, T = 8192, 65536
+b = cm.Batch(S, 1, T, flags=cm.EQ | cm.OUT_F32)
+b.set_eq(-1, cm.eq3())
+b.set_gain(-1, 1, 1000, [900])
+b.generate(cm.GEN_NOISE, 12345, T)
+for _ in range(2):
+    b.run(T)
+b.sync()
+out = (C.c_uint64 * 64)()
+cm.lib.cmhip_debug_read.argtypes = [C.c_void_p, C.c_void_p]
+assert cm.lib.cmhip_debug_read(b.h, out) == 0
+nsteps = out[40]
+print("G =", os.environ.get("CMHIP_EQ_G", "default"), "steps", nsteps)
+for w in range(16):
+    if out[2 * w + 1]:
+        print(f"wave {w:2d}: busy {out[2*w]/nsteps:8.1f} clk/step   total {out[2*w+1]/nsteps:8.1f} clk/step")
