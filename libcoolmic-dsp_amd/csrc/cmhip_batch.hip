@@ -167,6 +167,7 @@ struct cmhip_batch {
     std::vector<uint16_t> h_scale;         // the reference's master_gain_scale per stream
     std::vector<uint16_t> h_gain;          // [S][16]
     bool param_dirty;
+    bool all_identity;                     // no stream has a channel map (recomputed on upload)
     std::vector<EqParam> h_eq;
     unsigned int nsec;
     bool eq_dirty;
@@ -408,6 +409,7 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->parity = 0;
     b->snap_parity = 0;
     b->param_dirty = true;
+    b->all_identity = true;
     b->eq_dirty = false;
     b->nsec = 0;
     b->timing = false;
@@ -712,6 +714,10 @@ extern "C" int cmhip_batch_generate(cmhip_batch_t *b, int mode, uint32_t seed, s
 static int flush_params(cmhip_batch_t *b)
 {
     if (b->param_dirty) {
+        b->all_identity = true;
+        for (const auto &p : b->h_param)
+            if (!p.map_identity)
+                b->all_identity = false;
         HIP_TRY(hipMemcpyAsync(b->d_param, b->h_param.data(), b->h_param.size() * sizeof(StreamParam),
                                hipMemcpyHostToDevice, b->stream));
         b->param_dirty = false;
@@ -798,6 +804,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.stride = b->stride;
         a.plane = b->plane;
         a.chunks = 0;                      // the launcher sizes the tiles per kernel variant
+        a.identity_maps = b->all_identity ? 1u : 0u;
         a.parity = b->parity;
         HIP_TRY(launch_run(a, b->stream));
     }

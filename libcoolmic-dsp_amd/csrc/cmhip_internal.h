@@ -66,6 +66,7 @@ struct RunArgs {
     uint64_t       plane;          // floats between planes of the f32 output
     uint32_t       chunks;         // 4 KiB tiles (one wave each) per stream slot
     uint32_t       parity;         // which VuState::samples slot is current
+    uint32_t       identity_maps;  // 1 when no stream of the batch has a channel map
 };
 
 struct EqArgs {

@@ -384,6 +384,196 @@ __global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Wide path: 4, 8 or 16 channels with the identity channel map.  Same tile scheme and the
+// same packed arithmetic as k_run_fast; a 16-byte vector holds 8/C frames, so every vector
+// position has a fixed channel (for 16 channels: fixed per lane parity) and the per-channel
+// accumulators live in registers.  NS = min(C, 8) accumulator slots per lane: the half h of
+// dword i feeds slot 2*(i % (NS/2)) + h.
+
+template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U>
+__global__ __launch_bounds__(64) void k_run_wide(RunArgs a)
+{
+    constexpr u32 TILE_U = U;
+    constexpr u32 TILE_VEC = 64 * TILE_U;
+    constexpr u32 NS = C < 8 ? C : 8;            // accumulator slots per lane
+    constexpr u32 NG = NS / 2;                   // dword groups
+    constexpr u32 NCLS = C == 16 ? 2 : 1;        // lane classes (vector parity) for 16 channels
+    const u32 lane = threadIdx.x;
+    const u32 s = blockIdx.x / a.chunks;
+    const u32 k = blockIdx.x - s * a.chunks;
+
+    const u32 nfr = a.nframes ? a.nframes[s] : a.frames;
+    const u32 nsamp = nfr * (u32)C;
+    const u32 nfull = nsamp >> 3;
+    const u32 ntail = nsamp & 7u;                // only possible for 4 channels (one frame)
+    const u32 v0 = k * TILE_VEC;
+
+    VuState *vs = DO_VU ? a.vu + s : nullptr;
+    u64 base = 0;
+    if constexpr (DO_VU) {
+        base = vs->samples[a.parity];
+        if (k == 0 && lane == 0)
+            vs->samples[a.parity ^ 1u] = base + nsamp;
+    }
+    if (v0 >= nfull + (ntail ? 1u : 0u))
+        return;
+
+    const StreamParam *p = a.param + s;
+    const u32 magic = p->magic, shift = p->shift;
+    const u32 cls = C == 16 ? (lane & 1u) : 0u;  // v0 and 64*u are even: vector parity = lane parity
+    u32 g2[NS];
+#pragma unroll
+    for (u32 i = 0; i < NS; i++)
+        g2[i] = p->gain2[i + 8u * cls];
+
+    const int16_t *ins = a.in + (u64)s * a.stride;
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(ins);
+    int16_t *outs = WRITE_PCM ? a.out + (u64)s * a.stride : nullptr;
+    u32x4 *dst = reinterpret_cast<u32x4 *>(outs);
+    float *f32s = WRITE_F32 ? a.f32 + (u64)s * a.plane * C : nullptr;
+
+    u32 x[TILE_U][4];
+    bool full[TILE_U], tail[TILE_U];
+#pragma unroll
+    for (u32 u = 0; u < TILE_U; u++) {
+        const u32 v = v0 + 64u * u + lane;
+        full[u] = v < nfull;
+        tail[u] = ntail && v == nfull;
+        u32x4 w = {0, 0, 0, 0};
+        if (full[u])
+            w = __builtin_nontemporal_load(src + v);
+        x[u][0] = w.x; x[u][1] = w.y; x[u][2] = w.z; x[u][3] = w.w;
+        if (tail[u]) {
+            for (u32 j = 0; j < ntail; j++) {
+                const u32 val = (u32)(uint16_t)ins[(u64)v * 8 + j];
+#pragma unroll
+                for (u32 i = 0; i < 4; i++)
+                    if (i == (j >> 1))
+                        x[u][i] |= val << (16u * (j & 1u));
+            }
+        }
+    }
+
+    u32 qw[TILE_U][4];
+    PowAcc pw[NS];
+    u32 best[NS];
+#pragma unroll
+    for (u32 i = 0; i < NS; i++) {
+        pw[i] = PowAcc{0, 0, 0};
+        best[i] = 0;
+    }
+#pragma unroll
+    for (u32 u = 0; u < TILE_U; u++) {
+        const u32 v = v0 + 64u * u + lane;
+        u32 o[4], vmax[NG];
+#pragma unroll
+        for (u32 g = 0; g < NG; g++)
+            vmax[g] = 0;
+#pragma unroll
+        for (u32 i = 0; i < 4; i++) {
+            constexpr u32 dummy = 0;
+            (void)dummy;
+            const u32 g = i % NG;
+            qw[u][i] = gain2(x[u][i], g2[2 * g], g2[2 * g + 1], magic, shift, o[i]);
+            if constexpr (DO_VU) {
+                vmax[g] = pk_max(vmax[g], qw[u][i]);
+                pw[2 * g].add(qw[u][i] & 0xffffu);
+                pw[2 * g + 1].add(qw[u][i] >> 16);
+            }
+        }
+        if constexpr (DO_VU) {
+            const u32 tag = ((TILE_U - 1u - u) << 6) | (63u - lane);
+#pragma unroll
+            for (u32 g = 0; g < NG; g++) {
+                best[2 * g] = max(best[2 * g], (vmax[g] << 16) | tag);
+                best[2 * g + 1] = max(best[2 * g + 1], (vmax[g] & 0xffff0000u) | tag);
+            }
+        }
+        const u32 cnt = full[u] ? 8u : (tail[u] ? ntail : 0u);
+        if (full[u]) {
+            if constexpr (WRITE_PCM) {
+                const u32x4 ov = {o[0], o[1], o[2], o[3]};
+                __builtin_nontemporal_store(ov, dst + v);
+            }
+        } else if (tail[u]) {
+            if constexpr (WRITE_PCM) {
+                for (u32 j = 0; j < ntail; j++) {
+                    u32 ow = 0;
+#pragma unroll
+                    for (u32 i = 0; i < 4; i++)
+                        if (i == (j >> 1))
+                            ow = o[i];
+                    outs[(u64)v * 8 + j] = (int16_t)((ow >> (16u * (j & 1u))) & 0xffffu);
+                }
+            }
+        }
+        if constexpr (WRITE_F32) {
+            // planar float: consecutive lanes hold consecutive frames, so each of these
+            // stores writes a contiguous run of a plane
+#pragma unroll
+            for (u32 j = 0; j < 8; j++) {
+                if (j < cnt) {
+                    const u32 idx = v * 8u + j;
+                    const int q = (int)(short)((o[j >> 1] >> (16u * (j & 1u))) & 0xffffu);
+                    f32s[(u64)(idx % (u32)C) * a.plane + idx / (u32)C] = q * (1.0f / 32768.0f);
+                }
+            }
+        }
+    }
+
+    if constexpr (DO_VU) {
+#pragma unroll
+        for (u32 i = 0; i < NS; i++)
+            pw[i].flush();
+#pragma unroll
+        for (u32 c = 0; c < NCLS; c++) {
+            const bool mine = NCLS == 1 || cls == c;
+#pragma unroll
+            for (u32 sl = 0; sl < NS; sl++) {
+                const u64 sum = wave_add_u40(mine ? pw[sl].total : 0ull);
+                const u32 wkey = wave_max_u32(mine ? best[sl] : 0u);
+                const u32 ch = sl + 8u * c;
+                const u32 mag = wkey >> 16;
+                u64 gkey = 0;
+                if (mag) {
+                    const u32 uw = TILE_U - 1u - ((wkey >> 6) & (TILE_U - 1u));
+                    const u32 lw = 63u - (wkey & 63u);
+                    u32 Q[4], X[4];
+#pragma unroll
+                    for (u32 u = 0; u < TILE_U; u++) {
+                        if (uw == u) {
+#pragma unroll
+                            for (u32 i = 0; i < 4; i++) {
+                                Q[i] = (u32)__builtin_amdgcn_readlane((int)qw[u][i], (int)lw);
+                                X[i] = (u32)__builtin_amdgcn_readlane((int)x[u][i], (int)lw);
+                            }
+                        }
+                    }
+                    u32 first = 8, neg = 0;
+#pragma unroll
+                    for (u32 j = 0; j < 8; j++) {
+                        if (j % NS != sl)
+                            continue;
+                        const u32 m = (Q[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
+                        if (m == mag && first == 8) {
+                            first = j;
+                            neg = (X[j >> 1] >> (16u * (j & 1u) + 15u)) & 1u;
+                        }
+                    }
+                    gkey = make_key(mag, base + 8ull * (v0 + 64u * uw + lw) + first, neg);
+                }
+                if (lane == 0) {
+                    if (sum)
+                        atomicAdd(&vs->power[ch], sum);
+                    if (gkey)
+                        atomicMax(&vs->key[ch], gkey);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // General path: any channel count up to 16, any channel map.  One thread per frame.
 
 __global__ __launch_bounds__(256) void k_run_generic(RunArgs a, u32 blocks_per_stream)
@@ -507,6 +697,43 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
             CMHIP_FAST_C(2);
 #undef CMHIP_FAST_C
 #undef CMHIP_FAST
+    } else if ((a.channels == 4 || a.channels == 8 || a.channels == 16) && a.identity_maps) {
+        RunArgs b = a;
+        // tile size: the epilogue grows with the channel count, so 16 channels and read-only
+        // runs take 16 KiB tiles, the rest 8 KiB (tools/bench_generic.py)
+        const u32 wu = (a.channels == 16 || (!pcm && !f32)) ? 16u : 8u;
+        const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
+        b.chunks = (u32)((nvec + 64ull * wu - 1) / (64ull * wu));
+        if (b.chunks == 0)
+            b.chunks = 1;
+        if ((u64)b.chunks * a.streams >= (1ull << 31))
+            return hipErrorInvalidValue;
+        const u32 grid = a.streams * b.chunks;
+#define CMHIP_WIDE(C, P, F, V)                                                     \
+    do {                                                                           \
+        if (wu == 16u)                                                             \
+            hipLaunchKernelGGL((k_run_wide<C, P, F, V, 16>), dim3(grid), dim3(64), 0, st, b); \
+        else                                                                       \
+            hipLaunchKernelGGL((k_run_wide<C, P, F, V, 8>), dim3(grid), dim3(64), 0, st, b);  \
+    } while (0)
+#define CMHIP_WIDE_C(C)                                                            \
+    do {                                                                           \
+        if (pcm && !f32 && vu) CMHIP_WIDE(C, true, false, true);                   \
+        else if (!pcm && !f32 && vu) CMHIP_WIDE(C, false, false, true);            \
+        else if (pcm && !f32 && !vu) CMHIP_WIDE(C, true, false, false);            \
+        else if (pcm && f32 && vu) CMHIP_WIDE(C, true, true, true);                \
+        else if (!pcm && f32 && vu) CMHIP_WIDE(C, false, true, true);              \
+        else if (pcm && f32 && !vu) CMHIP_WIDE(C, true, true, false);              \
+        else if (!pcm && f32 && !vu) CMHIP_WIDE(C, false, true, false);            \
+    } while (0)
+        if (a.channels == 4)
+            CMHIP_WIDE_C(4);
+        else if (a.channels == 8)
+            CMHIP_WIDE_C(8);
+        else
+            CMHIP_WIDE_C(16);
+#undef CMHIP_WIDE_C
+#undef CMHIP_WIDE
     } else {
         u32 bps = (a.frames + 255u) / 256u;
         if (bps > 64u)

@@ -432,3 +432,57 @@ def test_full_size_config2_properties(gpu, oracle):
     bad = [s for s in range(S) if res2[s].as_dict() != full[s]]
     assert not bad, bad[:8]
     v.close()
+
+
+@pytest.mark.parametrize("C", [4, 8, 16])
+def test_wide_channel_kernels(gpu, oracle, C):
+    """4/8/16 channels with identity maps take k_run_wide: ragged lengths, per-stream gains,
+    in place and not, VU only, float planes, windows over two launches"""
+    cm = gpu
+    rng = np.random.default_rng(500 + C)
+    lens = [0, 1, 2, 3, 63, 64, 65, 127, 128, 129, 511, 1000, 1023, 1024, 1025, 3000]
+    S, T = len(lens), max(lens)
+    xs = [_rand_pcm(rng, lens[s] * C, ["full", "edges", "small"][s % 3]) for s in range(S)]
+    gas = []
+    for s in range(S):
+        if s % 4 == 0:
+            gas.append(None)
+        elif s % 4 == 1:
+            gas.append((C, int(rng.integers(1, 65536)), [int(v) for v in rng.integers(0, 65536, C)]))
+        elif s % 4 == 2:
+            gas.append((1, 1000, [int(rng.integers(0, 5000))]))
+        else:
+            gas.append((C, 1, [65535] * C))
+    wants = [_oracle_block(oracle, xs[s], C, gas[s], None) for s in range(S)]
+    for flags in (cm.OUT_PCM | cm.VU, cm.OUT_PCM | cm.VU | cm.INPLACE, cm.VU, cm.OUT_PCM,
+                  cm.OUT_F32 | cm.OUT_PCM | cm.VU, cm.OUT_F32):
+        b = cm.Batch(S, C, T, flags=flags)
+        for s in range(S):
+            if gas[s] is not None:
+                assert b.set_gain(s, *gas[s]) == 0
+            if lens[s]:
+                b.upload(s, xs[s])
+        b.run(T, frames_per_stream=lens)
+        for s in range(S):
+            if flags & cm.OUT_PCM:
+                got = b.download(s, lens[s]) if lens[s] else np.zeros(0, np.int16)
+                assert np.array_equal(got, wants[s]), (C, s, flags)
+            if flags & cm.OUT_F32 and lens[s]:
+                planar = oracle.to_f32_planar(wants[s], C)
+                for c in range(C):
+                    gotf = b.download_f32(s, c, lens[s])
+                    assert np.array_equal(gotf.view(np.uint32), planar[c].view(np.uint32)), (C, s, c)
+        if flags & cm.VU:
+            # second launch into the same window: the reversed block
+            for s in range(S):
+                if lens[s]:
+                    b.upload(s, xs[s][::-1].copy())
+            b.run(T, frames_per_stream=lens)
+            for s in range(S):
+                w2 = _oracle_block(oracle, xs[s][::-1].copy(), C, gas[s], None)
+                rc_o, r_o = _oracle_vu(oracle, [wants[s], w2], C)
+                rc_g, r_g = b.vu_result(s)
+                assert rc_g == rc_o, (C, s, flags)
+                if rc_o == 0:
+                    assert r_g.as_dict() == of.vu_result_dict(r_o), (C, s, flags)
+        b.close()
