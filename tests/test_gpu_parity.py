@@ -486,3 +486,48 @@ def test_wide_channel_kernels(gpu, oracle, C):
                 if rc_o == 0:
                     assert r_g.as_dict() == of.vu_result_dict(r_o), (C, s, flags)
         b.close()
+
+
+def test_batch_api_error_paths(gpu):
+    """argument checking of the C ABI (include/coolmic_hip.h): errors are numbers, never faults"""
+    import ctypes as C
+    cm = gpu
+    with pytest.raises(cm.CoolmicError):
+        cm.Batch(0, 2, 64)
+    with pytest.raises(cm.CoolmicError):
+        cm.Batch(1, 17, 64)
+    with pytest.raises(cm.CoolmicError):
+        cm.Batch(1, 2, 64, flags=0)
+    with pytest.raises(cm.CoolmicError):
+        cm.Batch(1, 2, 64, flags=cm.EQ | cm.OUT_F32)          # EQ needs mono
+    with pytest.raises(cm.CoolmicError):
+        cm.Batch(1, 1, 64, device=99)
+    b = cm.Batch(2, 2, 64, flags=cm.OUT_PCM | cm.VU)
+    assert b.set_gain(2, 2, 1000, [1, 1]) == cm.ERROR_INVAL       # stream out of range
+    assert b.set_gain(0, 3, 1000, [1, 1, 1]) == cm.ERROR_INVAL    # shape rule of the reference
+    assert b.set_gain(0, 2, 0, [1, 1]) == 0                       # disables
+    assert b.set_chmap(0, [0, 2]) == cm.ERROR_INVAL
+    assert b.set_eq(0, cm.eq3()) == cm.ERROR_INVAL                # batch without EQ
+    assert cm.lib.cmhip_batch_run(b.h, 65, None) == cm.ERROR_INVAL
+    assert cm.lib.cmhip_batch_run(b.h, 0, None) == 0
+    bad = (C.c_uint32 * 2)(10, 100)
+    assert cm.lib.cmhip_batch_run(b.h, 64, bad) == cm.ERROR_INVAL
+    x = np.zeros(65 * 2, dtype=np.int16)
+    assert cm.lib.cmhip_batch_upload(b.h, 0, x.ctypes.data, 65) == cm.ERROR_INVAL
+    assert cm.lib.cmhip_batch_upload(b.h, 2, x.ctypes.data, 1) == cm.ERROR_INVAL
+    assert cm.lib.cmhip_batch_upload(b.h, 0, None, 1) == cm.ERROR_FAULT
+    assert cm.lib.cmhip_batch_download_f32(b.h, 0, 0, x.ctypes.data, 1) == cm.ERROR_INVAL
+    assert b.vu_result(0)[0] == cm.ERROR_INVAL                   # nothing accounted yet
+    assert cm.lib.cmhip_batch_vu_collect(b.h, None, None) == cm.ERROR_FAULT
+    r = (cm.VuResult * 2)()
+    assert cm.lib.cmhip_batch_vu_collect(b.h, r, None) == cm.ERROR_INVAL    # no snapshot pending
+    b.vu_snapshot()
+    assert cm.lib.cmhip_batch_vu_snapshot(b.h) == cm.ERROR_BUSY
+    b.vu_collect()
+    assert cm.lib.cmhip_batch_run(None, 1, None) == cm.ERROR_FAULT
+    assert b"" != cm.lib.cmhip_last_error()
+    vonly = cm.Batch(1, 1, 64, flags=cm.VU)
+    assert cm.lib.cmhip_batch_download(vonly.h, 0, x.ctypes.data, 1) == cm.ERROR_INVAL
+    assert vonly.ceiling(1, 1) < 0                                # copy needs a PCM output
+    vonly.close()
+    b.close()
