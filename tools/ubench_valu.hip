@@ -26,6 +26,26 @@
         if (s == 0x12345678u) out[0] = s;                                                 \
     }
 
+
+#define BODY2(NAME, ASM)                                                                  \
+    __global__ __launch_bounds__(256) void k_##NAME(uint32_t *out, int iters, uint32_t a, \
+                                                     uint32_t b)                          \
+    {                                                                                     \
+        double x[CHAINS];                                                                 \
+        double bb = __hiloint2double(b, b);                                               \
+        for (int i = 0; i < CHAINS; i++) x[i] = __hiloint2double(threadIdx.x + i + a, threadIdx.x * 3 + i); \
+        for (int it = 0; it < iters; it++) {                                              \
+            _Pragma("unroll") for (int r = 0; r < REPS / CHAINS; r++) {                   \
+                _Pragma("unroll") for (int i = 0; i < CHAINS; i++) {                      \
+                    asm volatile(ASM : "+v"(x[i]) : "v"(bb));                             \
+                }                                                                         \
+            }                                                                             \
+        }                                                                                 \
+        double s = 0;                                                                     \
+        for (int i = 0; i < CHAINS; i++) s += x[i];                                       \
+        if (s == 0.12345) out[0] = 1;                                                     \
+    }
+
 BODY(add, "v_add_u32 %0, %0, %1")
 BODY(mul_u24, "v_mul_u32_u24 %0, %0, %1")
 BODY(mul_hi_u24, "v_mul_hi_u32_u24 %0, %0, %1")
@@ -46,6 +66,11 @@ BODY(xor_sdwa, "v_xor_b32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_
 BODY(lshr_s, "v_lshrrev_b32 %0, %2, %0")
 BODY(cvt_f32_u32, "v_cvt_f32_u32 %0, %0")
 BODY(mul_f32, "v_mul_f32 %0, %0, %1")
+BODY(fmac_f32, "v_fmac_f32 %0, %1, %1")
+BODY(fma_f32, "v_fma_f32 %0, %0, %1, %1")
+BODY2(pk_fma_f32, "v_pk_fma_f32 %0, %0, %1, %1")
+BODY2(pk_mul_f32, "v_pk_mul_f32 %0, %0, %1")
+BODY2(pk_add_f32, "v_pk_add_f32 %0, %0, %1")
 
 template <typename K>
 static void run(const char *name, K kern, uint32_t *d)
@@ -78,6 +103,6 @@ int main()
     RUN(add); RUN(mul_u24); RUN(mul_hi_u24); RUN(mul_lo); RUN(mul_hi); RUN(mad_u32_u16);
     RUN(mad_u32_u24); RUN(pk_max_u16); RUN(pk_sub_i16); RUN(pk_min_u16); RUN(cvt_pk_u16);
     RUN(perm); RUN(lshl_or); RUN(max3); RUN(alignbit); RUN(dot2_u16); RUN(xor_sdwa); RUN(lshr_s);
-    RUN(cvt_f32_u32); RUN(mul_f32);
+    RUN(cvt_f32_u32); RUN(mul_f32); RUN(fmac_f32); RUN(fma_f32); RUN(pk_fma_f32); RUN(pk_mul_f32); RUN(pk_add_f32);
     return 0;
 }
