@@ -129,6 +129,19 @@ struct PowAcc {
         if (++n == 3)
             flush();
     }
+    // square of one 16-bit half of a packed pair added in a single v_mad_u32_u16
+    __device__ __forceinline__ void add_lo(u32 pair)
+    {
+        asm("v_mad_u32_u16 %0, %1, %1, %0 op_sel:[0,0,0,0]" : "+v"(part) : "v"(pair));
+        if (++n == 3)
+            flush();
+    }
+    __device__ __forceinline__ void add_hi(u32 pair)
+    {
+        asm("v_mad_u32_u16 %0, %1, %1, %0 op_sel:[1,1,0,0]" : "+v"(part) : "v"(pair));
+        if (++n == 3)
+            flush();
+    }
     __device__ __forceinline__ void flush()
     {
         total += part;
@@ -213,31 +226,17 @@ constexpr u32 TILE_U_VUONLY_STEREO = 16;
 // over small tiles keep the chip-wide access window compact; on MI355X that is worth
 // ~15 % of HBM bandwidth over waves that each stream through tens of KiB
 // (tools/ubench_copy*.hip: 6.3-6.5 TB/s against 5.0-5.4 TB/s for read+write).
-template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U>
-__global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
+// FULL: the tile lies completely inside the stream's whole vectors -- no bounds tests, no
+// zero padding, no ragged tail; this is the case for all but the last tile of a stream.
+template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U, bool FULL>
+__device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 nsamp, u32 nfull, u32 ntail,
+                                          u64 base, VuState *vs)
 {
     constexpr u32 TILE_U = U;
     constexpr u32 TILE_VEC = 64 * TILE_U;
     const u32 lane = threadIdx.x;
-    const u32 s = blockIdx.x / a.chunks;         // stream
-    const u32 k = blockIdx.x - s * a.chunks;     // tile inside the stream
-
-    const u32 nfr = a.nframes ? a.nframes[s] : a.frames;
-    const u32 nsamp = nfr * (u32)C;
-    const u32 nfull = nsamp >> 3;                // whole 16-byte vectors
-    const u32 ntail = nsamp & 7u;                // samples in the partial last vector
     const u32 v0 = k * TILE_VEC;
-
-    VuState *vs = DO_VU ? a.vu + s : nullptr;
-    u64 base = 0;
-    if constexpr (DO_VU) {
-        // window position: read from one slot, the stream's first tile writes the other
-        base = vs->samples[a.parity];
-        if (k == 0 && lane == 0)
-            vs->samples[a.parity ^ 1u] = base + nsamp;
-    }
-    if (v0 >= nfull + (ntail ? 1u : 0u))
-        return;
+    (void)nsamp;
 
     const StreamParam *p = a.param + s;
     const u32 magic = p->magic, shift = p->shift, perm2 = p->perm2;
@@ -255,8 +254,8 @@ __global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
 #pragma unroll
     for (u32 u = 0; u < TILE_U; u++) {
         const u32 v = v0 + 64u * u + lane;
-        full[u] = v < nfull;
-        tail[u] = ntail && v == nfull;
+        full[u] = FULL || v < nfull;
+        tail[u] = !FULL && ntail && v == nfull;
         u32x4 w = {0, 0, 0, 0};
         if (full[u])
             w = __builtin_nontemporal_load(src + v);
@@ -287,8 +286,8 @@ __global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
             qw[u][i] = gain2(x[u][i], g2lo, g2hi, magic, shift, o[i]);
             if constexpr (DO_VU) {
                 vmax = pk_max(vmax, qw[u][i]);
-                pw[0].add(qw[u][i] & 0xffffu);
-                pw[C - 1].add(qw[u][i] >> 16);
+                pw[0].add_lo(qw[u][i]);
+                pw[C - 1].add_hi(qw[u][i]);
             }
         }
         if constexpr (DO_VU) {
@@ -381,6 +380,36 @@ __global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
                 atomicMax(&vs->key[lane], skey);
         }
     }
+}
+
+template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U>
+__global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
+{
+    constexpr u32 TILE_VEC = 64 * U;
+    const u32 lane = threadIdx.x;
+    const u32 s = blockIdx.x / a.chunks;         // stream
+    const u32 k = blockIdx.x - s * a.chunks;     // tile inside the stream
+
+    const u32 nfr = a.nframes ? a.nframes[s] : a.frames;
+    const u32 nsamp = nfr * (u32)C;
+    const u32 nfull = nsamp >> 3;                // whole 16-byte vectors
+    const u32 ntail = nsamp & 7u;                // samples in the partial last vector
+    const u32 v0 = k * TILE_VEC;
+
+    VuState *vs = DO_VU ? a.vu + s : nullptr;
+    u64 base = 0;
+    if constexpr (DO_VU) {
+        // window position: read from one slot, the stream's first tile writes the other
+        base = vs->samples[a.parity];
+        if (k == 0 && lane == 0)
+            vs->samples[a.parity ^ 1u] = base + nsamp;
+    }
+    if (v0 >= nfull + (ntail ? 1u : 0u))
+        return;
+    if (v0 + TILE_VEC <= nfull)
+        fast_tile<C, WRITE_PCM, WRITE_F32, DO_VU, U, true>(a, s, k, nsamp, nfull, ntail, base, vs);
+    else
+        fast_tile<C, WRITE_PCM, WRITE_F32, DO_VU, U, false>(a, s, k, nsamp, nfull, ntail, base, vs);
 }
 
 // ---------------------------------------------------------------------------
@@ -477,8 +506,8 @@ __global__ __launch_bounds__(64) void k_run_wide(RunArgs a)
             qw[u][i] = gain2(x[u][i], g2[2 * g], g2[2 * g + 1], magic, shift, o[i]);
             if constexpr (DO_VU) {
                 vmax[g] = pk_max(vmax[g], qw[u][i]);
-                pw[2 * g].add(qw[u][i] & 0xffffu);
-                pw[2 * g + 1].add(qw[u][i] >> 16);
+                pw[2 * g].add_lo(qw[u][i]);
+                pw[2 * g + 1].add_hi(qw[u][i]);
             }
         }
         if constexpr (DO_VU) {
