@@ -1006,8 +1006,13 @@ void k_eq_pipe(EqArgs a)
         const float *c = a.eq[sl].coef[sec];
         const float *st = a.state[sl].s[sec];
         if (is_fir) {
-            c0 = c[0]; c1 = c[1]; c2 = c[2];
-            h1 = st[0]; h2 = st[1];
+            // section 0 sees integer-valued samples (see the loaders): fold the 2^-15 in here.
+            // Its history is kept in the same unscaled form inside the kernel and converted
+            // at the EqState boundary, so the state stays what the oracle's would be.
+            const float k = sec == 0 ? (1.0f / 32768.0f) : 1.0f;
+            const float ki = sec == 0 ? 32768.0f : 1.0f;
+            c0 = c[0] * k; c1 = c[1] * k; c2 = c[2] * k;
+            h1 = st[0] * ki; h2 = st[1] * ki;
         } else {
             c1 = -c[3]; c2 = -c[4];
             h1 = st[2]; h2 = st[3];
@@ -1029,7 +1034,7 @@ void k_eq_pipe(EqArgs a)
         fetch(0);
 
 #ifdef CMHIP_EQ_STAMPS
-    u64 st_busy = 0;
+    u64 st_busy = 0, st_read = 0;
     const u64 st_begin = __builtin_readcyclecounter();
 #endif
     for (u32 step = 0; step < nsteps; step++) {
@@ -1054,13 +1059,24 @@ void k_eq_pipe(EqArgs a)
                                 w[q] |= val << (16u * (j & 1u));
                     }
                 }
+                // gain in integers (exact), then straight to float: the magnitude is converted,
+                // the sign bit of the sample is copied in, and one med3 is the int16 saturation.
+                // The 2^-15 of "x / 32768.f" is NOT applied here: section 0 uses coefficients
+                // scaled by 2^-15 instead, which is bit-identical (power-of-two scaling commutes
+                // with every rounding in the chain) and saves a multiply per sample.
                 float f[8];
 #pragma unroll
                 for (u32 q = 0; q < 4; q++) {
-                    u32 o;
-                    gain2(w[q], l_g2, l_g2, l_magic, l_shift, o);
-                    f[2 * q] = (float)(int)(short)(o & 0xffffu) * (1.0f / 32768.0f);
-                    f[2 * q + 1] = (float)((int)o >> 16) * (1.0f / 32768.0f);
+                    const u32 sg = pk_sign(w[q]);
+                    const u32 aw = pk_sub(w[q] ^ sg, sg);
+                    const u32 n0 = __umul24(aw & 0xffffu, l_g2);
+                    const u32 n1 = __umul24(aw >> 16, l_g2);
+                    const float m0 = (float)(__umulhi(n0, l_magic) >> l_shift);
+                    const float m1 = (float)(__umulhi(n1, l_magic) >> l_shift);
+                    const u32 b0 = (__builtin_bit_cast(u32, m0) & 0x7fffffffu) | ((w[q] << 16) & 0x80000000u);
+                    const u32 b1 = (__builtin_bit_cast(u32, m1) & 0x7fffffffu) | (w[q] & 0x80000000u);
+                    f[2 * q] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, b0), -32768.0f, 32767.0f);
+                    f[2 * q + 1] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, b1), -32768.0f, 32767.0f);
                 }
                 float4 *dstx = reinterpret_cast<float4 *>(X + l_r * EP_ROW + l_t8);
                 dstx[0] = make_float4(f[0], f[1], f[2], f[3]);
@@ -1083,6 +1099,10 @@ void k_eq_pipe(EqArgs a)
 #pragma unroll
                     for (u32 t = 0; t < EP_TB / 4; t++)
                         v[t] = reinterpret_cast<const float4 *>(in)[t];
+#ifdef CMHIP_EQ_STAMPS
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    st_read += __builtin_readcyclecounter() - st_t0;
+#endif
                     if (is_fir) {
 #pragma unroll
                         for (u32 t = 0; t < EP_TB / 4; t++) {
@@ -1159,6 +1179,7 @@ void k_eq_pipe(EqArgs a)
     if (blockIdx.x == 7 && lane == 0 && a.dbg) {     // per-role busy cycles (tools/eq_stamps.py)
         a.dbg[2 * wave] = st_busy;
         a.dbg[2 * wave + 1] = __builtin_readcyclecounter() - st_begin;
+        a.dbg[41 + wave] = st_read;
         a.dbg[40] = nsteps;
     }
 #endif
@@ -1166,7 +1187,8 @@ void k_eq_pipe(EqArgs a)
     if (has_sec && live) {
         float *st = a.state[sl].s[sec];
         if (is_fir) {
-            st[0] = h1; st[1] = h2;
+            const float k = sec == 0 ? (1.0f / 32768.0f) : 1.0f;
+            st[0] = h1 * k; st[1] = h2 * k;
         } else {
             st[2] = h1; st[3] = h2;
         }

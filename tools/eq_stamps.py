@@ -24,4 +24,4 @@ nsteps = out[40]
 print("G =", os.environ.get("CMHIP_EQ_G", "default"), "steps", nsteps)
 for w in range(16):
     if out[2 * w + 1]:
-        print(f"wave {w:2d}: busy {out[2*w]/nsteps:8.1f} clk/step   total {out[2*w+1]/nsteps:8.1f} clk/step")
+        print(f"wave {w:2d}: busy {out[2*w]/nsteps:8.1f} clk/step   total {out[2*w+1]/nsteps:8.1f} clk/step   until LDS rows loaded {out[41+w]/nsteps:8.1f}")
