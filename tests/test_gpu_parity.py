@@ -531,3 +531,67 @@ def test_batch_api_error_paths(gpu):
     assert vonly.ceiling(1, 1) < 0                                # copy needs a PCM output
     vonly.close()
     b.close()
+
+
+@pytest.mark.parametrize("C", [1, 2, 4, 3])
+def test_random_sessions_match_per_stream_oracle(gpu, oracle, C):
+    """long random sessions: ragged blocks, gain / map changes between launches, results of
+    random streams at random times, whole-batch snapshots in between -- every result and
+    every PCM block must equal what one oracle transform+vumeter per stream produces"""
+    cm = gpu
+    rng = np.random.default_rng(9000 + C)
+    S, T = 12, 2500
+    b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU)
+    gains = [None] * S                                 # (channels, scale, gains) or None
+    maps = [None] * S
+    windows = [oracle.vu_new(C) for _ in range(S)]
+
+    def check_result(s, rc, r):
+        rc_o, r_o = oracle.vu_result(windows[s])        # resets the oracle window on success
+        assert rc == rc_o, (C, s)
+        if rc_o == 0:
+            assert r.as_dict() == of.vu_result_dict(r_o), (C, s)
+
+    for launch in range(40):
+        for s in range(S):
+            roll = rng.integers(0, 10)
+            if roll == 0:
+                gains[s] = (C, int(rng.integers(1, 4000)), [int(v) for v in rng.integers(0, 5000, C)])
+                assert b.set_gain(s, *gains[s]) == 0
+            elif roll == 1:
+                gains[s] = None
+                assert b.set_gain(s, 0, 0, None) == 0
+            elif roll == 2 and C <= 2:
+                maps[s] = [int(v) for v in rng.integers(0, C, C)]
+                assert b.set_chmap(s, maps[s]) == 0
+            elif roll == 3:
+                maps[s] = None
+                assert b.set_chmap(s, None) == 0
+        lens = [int(v) for v in rng.integers(0, T + 1, S)]
+        if launch % 7 == 0:
+            lens = [T] * S
+        xs = [_rand_pcm(rng, lens[s] * C, ["full", "edges", "small"][int(rng.integers(0, 3))])
+              for s in range(S)]
+        for s in range(S):
+            if lens[s]:
+                b.upload(s, xs[s])
+        b.run(T, frames_per_stream=lens)
+        for s in range(S):
+            want = _oracle_block(oracle, xs[s], C, gains[s], maps[s])
+            if lens[s]:
+                assert np.array_equal(b.download(s, lens[s]), want), (C, launch, s)
+            oracle.vu_accumulate(windows[s], want)
+        what = rng.integers(0, 4)
+        if what == 0:                                   # some single results
+            for s in rng.choice(S, 3, replace=False):
+                rc, r = b.vu_result(int(s))
+                check_result(int(s), rc, r)
+        elif what == 1:                                 # all windows at once
+            res, rcs = b.vu_results()
+            for s in range(S):
+                if rcs[s] == 0:
+                    check_result(s, 0, res[s])
+                else:
+                    assert windows[s].result.frames == 0
+                    oracle.lib.oracle_vumeter_reset(windows[s])
+    b.close()
