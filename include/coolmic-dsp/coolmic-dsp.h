@@ -30,6 +30,7 @@ extern "C" {
 /* feature names this build can report (ref: coolmic-dsp.h:53-58 for the driver ones) */
 #define COOLMIC_FEATURE_DRIVER_NULL     "driver:null"
 #define COOLMIC_FEATURE_DRIVER_SINE     "driver:sine"
+#define COOLMIC_FEATURE_DRIVER_STDIO    "driver:stdio"
 #define COOLMIC_FEATURE_ACCEL_HIP       "accel:hip/gfx950"
 
 /* static text for an error number (ref: src/coolmic-dsp.c, coolmic_error2string) */

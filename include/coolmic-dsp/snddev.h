@@ -20,6 +20,7 @@ extern "C" {
 #define COOLMIC_DSP_SNDDEV_DRIVER_AUTO   NULL
 #define COOLMIC_DSP_SNDDEV_DRIVER_NULL   "null"
 #define COOLMIC_DSP_SNDDEV_DRIVER_SINE   "sine"
+#define COOLMIC_DSP_SNDDEV_DRIVER_STDIO  "stdio"    /* raw PCM file replay; device = file name */
 
 #define COOLMIC_DSP_SNDDEV_RX    0x0001
 #define COOLMIC_DSP_SNDDEV_TX    0x0002
@@ -28,7 +29,8 @@ extern "C" {
 typedef struct coolmic_snddev coolmic_snddev_t;
 
 /* NULL for rate/channels/flags of 0, an unknown driver, or a driver that refuses
- * the format (sine: mono only, rate must be 8/16/24/32/44/44.1/48/96 kHz) */
+ * the format (sine: mono only, rate must be 8/16/24/32/44/44.1/48/96 kHz; stdio: the file
+ * must open for reading, capture only) */
 coolmic_snddev_t   *coolmic_snddev_new(const char *name, igloo_ro_t associated, const char *driver,
                                        void *device, uint_least32_t rate, unsigned int channels,
                                        int flags, ssize_t buffer);

@@ -160,13 +160,19 @@ __device__ __forceinline__ void store_f32(float *f32s, u64 plane, u32 v, const u
         f[2 * i] = (float)(int)(short)(o[i] & 0xffffu) * k;
         f[2 * i + 1] = (float)((int)o[i] >> 16) * k;
     }
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     if constexpr (C == 1) {
-        float4 *p = reinterpret_cast<float4 *>(f32s + (u64)v * 8);
-        p[0] = make_float4(f[0], f[1], f[2], f[3]);
-        p[1] = make_float4(f[4], f[5], f[6], f[7]);
+        // two 16-byte halves of one 32-byte run per lane: each instruction writes half of
+        // every line, so these stay ordinary stores and L2 merges them (non-temporal ones
+        // measured 20 % slower here; the stereo planes below write whole lines and gain 5 %)
+        f32x4 *p = reinterpret_cast<f32x4 *>(f32s + (u64)v * 8);
+        const f32x4 lo = {f[0], f[1], f[2], f[3]}, hi = {f[4], f[5], f[6], f[7]};
+        p[0] = lo;
+        p[1] = hi;
     } else {
-        *reinterpret_cast<float4 *>(f32s + (u64)v * 4) = make_float4(f[0], f[2], f[4], f[6]);
-        *reinterpret_cast<float4 *>(f32s + plane + (u64)v * 4) = make_float4(f[1], f[3], f[5], f[7]);
+        const f32x4 l = {f[0], f[2], f[4], f[6]}, r = {f[1], f[3], f[5], f[7]};
+        __builtin_nontemporal_store(l, reinterpret_cast<f32x4 *>(f32s + (u64)v * 4));
+        __builtin_nontemporal_store(r, reinterpret_cast<f32x4 *>(f32s + plane + (u64)v * 4));
     }
 }
 

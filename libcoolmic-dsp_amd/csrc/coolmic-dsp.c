@@ -30,7 +30,7 @@ const char *coolmic_error2string(const int error)
 const char *coolmic_features(void)
 {
     return "features " COOLMIC_FEATURE_DRIVER_NULL " " COOLMIC_FEATURE_DRIVER_SINE
-           " " COOLMIC_FEATURE_ACCEL_HIP;
+           " " COOLMIC_FEATURE_DRIVER_STDIO " " COOLMIC_FEATURE_ACCEL_HIP;
 }
 
 /* whole-word match inside the space separated list */

@@ -1,15 +1,16 @@
 /* snddev.c -- capture sources "null" and "sine" behind the reference's snddev API
  * (contract: <coolmic-dsp/snddev.h>; ref: src/snddev.c:60-169, src/snddev_null.c,
- * src/snddev_sine.c:101-193).  These are data sources for the chain and stay on
- * the CPU; hardware drivers and playback are out of scope. */
+ * src/snddev_sine.c:101-193, src/snddev_stdio.c:50-78).  These are data sources for the
+ * chain and stay on the CPU; hardware drivers and playback are out of scope. */
 #define COOLMIC_COMPONENT "libcoolmic-dsp/snddev"
 #include "host_internal.h"
 #include <coolmic-dsp/snddev.h>
 
+#include <stdio.h>
 #include <string.h>
 #include <strings.h>
 
-enum source_kind { SOURCE_NULL, SOURCE_SINE };
+enum source_kind { SOURCE_NULL, SOURCE_SINE, SOURCE_STDIO };
 
 struct coolmic_snddev {
     coolmic_ro_base_t base;
@@ -18,9 +19,18 @@ struct coolmic_snddev {
     int16_t period[96];
     size_t period_bytes;
     size_t phase;
+    /* stdio: raw PCM file being replayed */
+    FILE *file;
 };
 
-static const coolmic_ro_type_t snddev_type = {"coolmic_snddev_t", sizeof(coolmic_snddev_t), NULL};
+static void snddev_destroy(void *self)
+{
+    coolmic_snddev_t *dev = self;
+    if (dev->file != NULL)
+        fclose(dev->file);
+}
+
+static const coolmic_ro_type_t snddev_type = {"coolmic_snddev_t", sizeof(coolmic_snddev_t), snddev_destroy};
 
 static ssize_t snddev_read(void *userdata, void *buffer, size_t len)
 {
@@ -30,6 +40,8 @@ static ssize_t snddev_read(void *userdata, void *buffer, size_t len)
                         "Read request, buffer=%p, len=%zu", buffer, len);
     if (dev->kind == SOURCE_NULL) {
         memset(buffer, 0, len);                  /* silence, always the full request */
+    } else if (dev->kind == SOURCE_STDIO) {
+        return (ssize_t)fread(buffer, 1, len, dev->file);   /* 0 at end of file */
     } else {
         /* endless repetition of the period, byte granular: a read may stop in the
          * middle of a sample and the next one continues there */
@@ -66,8 +78,9 @@ coolmic_snddev_t *coolmic_snddev_new(const char *name, igloo_ro_t associated, co
     enum source_kind kind;
     int16_t period[96];
     size_t n = 0;
+    FILE *file = NULL;
 
-    (void)device, (void)buffer;
+    (void)buffer;
     if (!rate || !channels || !flags)
         return NULL;
     if (driver == NULL)                          /* AUTO: no hardware here, so "null" */
@@ -78,14 +91,27 @@ coolmic_snddev_t *coolmic_snddev_new(const char *name, igloo_ro_t associated, co
         kind = SOURCE_SINE;
         if (channels != 1 || coolmic_sine_period(rate, period, &n) != COOLMIC_ERROR_NONE)
             return NULL;                         /* mono, table rates only */
+    } else if (strcasecmp(driver, COOLMIC_DSP_SNDDEV_DRIVER_STDIO) == 0) {
+        /* raw PCM replay: `device` is the file name (ref: src/snddev_stdio.c:50-78), RX only */
+        kind = SOURCE_STDIO;
+        if (device == NULL || *(const char *)device == 0 || !(flags & COOLMIC_DSP_SNDDEV_RX) ||
+            (flags & COOLMIC_DSP_SNDDEV_TX))
+            return NULL;
+        file = fopen(device, "rb");
+        if (file == NULL)
+            return NULL;
     } else {
         return NULL;
     }
 
     dev = coolmic_ro_new_raw(&snddev_type, name, associated);
-    if (dev == NULL)
+    if (dev == NULL) {
+        if (file != NULL)
+            fclose(file);
         return NULL;
+    }
     dev->kind = kind;
+    dev->file = file;
     if (kind == SOURCE_SINE) {
         memcpy(dev->period, period, n * sizeof(int16_t));
         dev->period_bytes = n * sizeof(int16_t);

@@ -303,3 +303,24 @@ def test_group_needs_a_gpu(cm):
     assert not cm.lib.coolmic_group_new(None, None, 48000, 2, 4, 512, 2)
     assert not cm.lib.coolmic_group_new(None, None, 0, 2, 4, 512, 2)
     assert cm.lib.coolmic_group_pump(None) == cm.ERROR_FAULT
+
+
+def test_stdio_source_replays_a_raw_pcm_file(cm, tmp_path):
+    # ref: src/snddev_stdio.c:50-78 -- device is the file name, read() is fread()
+    data = bytes(range(256)) * 9
+    f = tmp_path / "capture.pcm"
+    f.write_bytes(data)
+    new = cm.lib.coolmic_snddev_new
+    assert not new(None, None, b"stdio", None, 48000, 2, 1, -1)                       # no file name
+    assert not new(None, None, b"stdio", str(tmp_path / "missing").encode(), 48000, 2, 1, -1)
+    assert not new(None, None, b"stdio", str(f).encode(), 48000, 2, 2, -1)            # playback: out of scope
+    name = str(f).encode()
+    d = new(None, None, b"stdio", name, 48000, 2, 1, -1)
+    assert d
+    h = cm.IoHandle(cm.lib.coolmic_snddev_get_iohandle(d))
+    cm.lib.coolmic_ro_unref(d)
+    assert h.read(1000) == (1000, data[:1000])
+    assert h.read(5000) == (len(data) - 1000, data[1000:])     # short read at end of file
+    assert h.read(10) == (0, b"")
+    h.unref()
+    assert cm.lib.coolmic_feature_check(b"driver:stdio") == 1
