@@ -95,6 +95,13 @@ void   *cmhip_batch_hip_stream(cmhip_batch_t *b);         /* the hipStream_t lau
 /* ---- moving PCM (asynchronous on the batch's stream) ---------------------- */
 int cmhip_batch_upload(cmhip_batch_t *b, unsigned int stream, const int16_t *pcm, size_t frames);
 int cmhip_batch_download(cmhip_batch_t *b, unsigned int stream, int16_t *pcm, size_t frames);
+/* whole-batch forms: `host` mirrors the device layout, int16 [S][cmhip_batch_stride()], and
+ * one copy moves every slot; asynchronous on the batch's stream (cmhip_batch_sync() to wait).
+ * Pinned memory from cmhip_host_alloc() gives full PCIe speed and real asynchrony. */
+int   cmhip_batch_upload_all(cmhip_batch_t *b, const int16_t *host, size_t frames);
+int   cmhip_batch_download_all(cmhip_batch_t *b, int16_t *host, size_t frames);
+void *cmhip_host_alloc(size_t bytes);             /* NULL on failure */
+void  cmhip_host_free(void *p);
 /* reads an input slot back (generated or uploaded PCM); synchronises */
 int cmhip_batch_download_input(cmhip_batch_t *b, unsigned int stream, int16_t *pcm, size_t frames);
 int cmhip_batch_download_f32(cmhip_batch_t *b, unsigned int stream, unsigned int channel,

@@ -89,6 +89,10 @@ SIGNATURES = {
     "cmhip_batch_hip_stream": (_vp, [_vp]),
     "cmhip_batch_upload": (C.c_int, [_vp, C.c_uint, _vp, C.c_size_t]),
     "cmhip_batch_download": (C.c_int, [_vp, C.c_uint, _vp, C.c_size_t]),
+    "cmhip_batch_upload_all": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "cmhip_batch_download_all": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "cmhip_host_alloc": (_vp, [C.c_size_t]),
+    "cmhip_host_free": (None, [_vp]),
     "cmhip_batch_download_input": (C.c_int, [_vp, C.c_uint, _vp, C.c_size_t]),
     "cmhip_batch_download_f32": (C.c_int, [_vp, C.c_uint, C.c_uint, _vp, C.c_size_t]),
     "cmhip_batch_generate": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_size_t, C.c_uint64,
@@ -272,6 +276,12 @@ class Batch:
                                                             out.ctypes.data, frames))
         return out
 
+    def upload_all(self, host_ptr, frames):
+        _check("upload_all", lib.cmhip_batch_upload_all(self.h, host_ptr, frames))
+
+    def download_all(self, host_ptr, frames):
+        _check("download_all", lib.cmhip_batch_download_all(self.h, host_ptr, frames))
+
     def generate(self, mode, seed, frames, first_global=0, global_step=1, frame_offset=0):
         _check("generate", lib.cmhip_batch_generate(self.h, mode, seed & 0xFFFFFFFF, frames,
                                                     first_global, global_step, frame_offset))
@@ -353,6 +363,25 @@ class Batch:
     @property
     def dev_out(self):
         return lib.cmhip_batch_dev_out(self.h)
+
+
+class PinnedPcm:
+    """pinned host mirror of a batch's PCM slots: numpy view int16 [S][stride]"""
+
+    def __init__(self, batch):
+        self.shape = (batch.streams, batch.stride)
+        self.nbytes = batch.streams * batch.stride * 2
+        self.ptr = lib.cmhip_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise CoolmicError("cmhip_host_alloc", ERROR_NOMEM)
+        buf = (C.c_int16 * (self.nbytes // 2)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=np.int16).reshape(self.shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib.cmhip_host_free(self.ptr)
+            self.ptr = None
 
 
 def node_finish(words, channels, rate=48000):

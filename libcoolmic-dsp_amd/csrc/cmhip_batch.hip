@@ -629,6 +629,54 @@ extern "C" int cmhip_batch_upload(cmhip_batch_t *b, unsigned int stream, const i
     return COOLMIC_ERROR_NONE;
 }
 
+// whole-batch transfers: one copy for all slots, asynchronous on the batch's stream.  `host`
+// mirrors the device layout [S][stride] (use cmhip_host_alloc for pinned memory, which is
+// what makes the copy asynchronous and full speed).
+extern "C" int cmhip_batch_upload_all(cmhip_batch_t *b, const int16_t *host, size_t frames)
+{
+    if (!b || !host)
+        return fail(COOLMIC_ERROR_FAULT, "upload_all: NULL argument");
+    if (frames == 0 || frames > b->d.max_frames)
+        return fail(COOLMIC_ERROR_INVAL, "upload_all: frames out of range");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    const size_t span = ((size_t)(b->d.streams - 1) * b->stride + frames * b->d.channels) * sizeof(int16_t);
+    HIP_TRY(hipMemcpyAsync(b->d_in, host, span, hipMemcpyHostToDevice, b->stream));
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_download_all(cmhip_batch_t *b, int16_t *host, size_t frames)
+{
+    if (!b || !host)
+        return fail(COOLMIC_ERROR_FAULT, "download_all: NULL argument");
+    if (!b->d_out)
+        return fail(COOLMIC_ERROR_INVAL, "download_all: batch has no PCM output");
+    if (frames == 0 || frames > b->d.max_frames)
+        return fail(COOLMIC_ERROR_INVAL, "download_all: frames out of range");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    const size_t span = ((size_t)(b->d.streams - 1) * b->stride + frames * b->d.channels) * sizeof(int16_t);
+    HIP_TRY(hipMemcpyAsync(host, b->d_out, span, hipMemcpyDeviceToHost, b->stream));
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" void *cmhip_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(COOLMIC_ERROR_NOMEM, "cmhip_host_alloc: %zu bytes of pinned memory", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void cmhip_host_free(void *p)
+{
+    if (p)
+        (void)hipHostFree(p);
+}
+
 extern "C" int cmhip_batch_download(cmhip_batch_t *b, unsigned int stream, int16_t *pcm,
                                     size_t frames)
 {
