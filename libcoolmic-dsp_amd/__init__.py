@@ -147,6 +147,11 @@ SIGNATURES = {
     "coolmic_tee_new": (_vp, [C.c_char_p, _vp, C.c_size_t]),
     "coolmic_tee_attach_iohandle": (C.c_int, [_vp, _vp]),
     "coolmic_tee_get_iohandle": (_vp, [_vp, ssize_t]),
+    # include/coolmic-dsp/util.h
+    "coolmic_util_ahsv2argb": (C.c_uint32, [C.c_double, C.c_double, C.c_double, C.c_double]),
+    "coolmic_util_power2hue": (C.c_double, [C.c_double, C.c_char_p]),
+    "coolmic_util_peak2hue": (C.c_double, [C.c_int16, C.c_char_p]),
+    "coolmic_util_vu_argb": (None, [_vp, C.c_size_t, C.c_char_p, _vp, _vp]),
     # include/coolmic-dsp/group.h
     "coolmic_group_new": (_vp, [C.c_char_p, _vp, C.c_uint32, C.c_uint, C.c_uint, C.c_size_t, C.c_uint]),
     "coolmic_group_add_stream": (C.c_int, [_vp, _vp]),

@@ -491,6 +491,61 @@ void oracle_eq_run_mono(const oracle_gain_t *g, const oracle_biquad_t *q, unsign
 }
 
 /* ------------------------------------------------------------------------- */
+/* VU presentation helpers.  ref: src/util.c:30-138                           */
+
+static uint32_t oracle_component(double x)               /* :30-44 */
+{
+    uint32_t v;
+    if (x >= 1.)
+        x = 1.;
+    else if (x <= 0.)
+        x = 0.;
+    v = (uint32_t)(x * 255.);
+    if (v > 255)
+        v = 255;
+    return v;
+}
+
+uint32_t oracle_ahsv2argb(double alpha, double hue, double saturation, double value)
+{
+    int h1 = (int)(double)(hue / (M_PI / 3.));           /* :60 */
+    double f = hue - (double)h1;                          /* :61, sextant number subtracted */
+    double p = value * (1. - saturation);
+    double q = value * (1. - saturation * f);
+    double t = value * (1. - saturation * (1. - f));
+    double rgb[3] = {0., 0., 0.};
+
+    if (h1 == 0 || h1 == 6) { rgb[0] = value; rgb[1] = t; rgb[2] = p; }
+    else if (h1 == 1)       { rgb[0] = q; rgb[1] = value; rgb[2] = p; }
+    else if (h1 == 2)       { rgb[0] = p; rgb[1] = value; rgb[2] = t; }
+    else if (h1 == 3)       { rgb[0] = p; rgb[1] = q; rgb[2] = value; }
+    else if (h1 == 4)       { rgb[0] = t; rgb[1] = p; rgb[2] = value; }
+    else if (h1 == 5)       { rgb[0] = value; rgb[1] = p; rgb[2] = q; }
+    return (oracle_component(alpha) << 24) + (oracle_component(rgb[0]) << 16) +
+           (oracle_component(rgb[1]) << 8) + oracle_component(rgb[2]);
+}
+
+double oracle_power2hue(double power)                    /* :108-120 */
+{
+    if (power < -20.)
+        return M_PI * 2. / 3.;
+    else if (power >= 0)
+        return 0;
+    return pow(sin(M_PI * power / 40.), 2.) * M_PI * 2. / 3.;
+}
+
+double oracle_peak2hue(int16_t peak)                     /* :124-138 */
+{
+    if (peak == -32768 || peak == 32767)
+        return 0.;
+    else if (peak < -30000 || peak > 30000)
+        return 0.43;
+    else if (peak < -28000 || peak > 28000)
+        return 1.;
+    return M_PI * 2. / 3.;
+}
+
+/* ------------------------------------------------------------------------- */
 /* timing helpers for the cpu_baseline leg of bench.py                        */
 
 static double now_s(void)

@@ -100,6 +100,9 @@ def load():
         "oracle_eq3_design": (None, [P(Biquad), C.c_double]),
         "oracle_eq_run_mono": (None, [P(Gain), P(Biquad), C.c_uint, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_size_t]),
+        "oracle_ahsv2argb": (C.c_uint32, [C.c_double, C.c_double, C.c_double, C.c_double]),
+        "oracle_power2hue": (C.c_double, [C.c_double]),
+        "oracle_peak2hue": (C.c_double, [C.c_int16]),
         "oracle_bench_block": (C.c_double, [C.c_uint, C.c_uint, C.c_uint, C.c_size_t, C.c_void_p,
                                             C.c_uint16, P(C.c_uint16), C.c_uint32,
                                             P(C.c_uint64)]),

@@ -16,6 +16,7 @@ HEADERS = [
     "include/coolmic-dsp/vumeter.h",
     "include/coolmic-dsp/snddev.h",
     "include/coolmic-dsp/tee.h",
+    "include/coolmic-dsp/util.h",
     "include/coolmic-dsp/group.h",
 ]
 DECL = re.compile(r"\b((?:cmhip|coolmic)_[a-z0-9_]+)\s*\(")

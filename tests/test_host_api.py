@@ -324,3 +324,38 @@ def test_stdio_source_replays_a_raw_pcm_file(cm, tmp_path):
     assert h.read(10) == (0, b"")
     h.unref()
     assert cm.lib.coolmic_feature_check(b"driver:stdio") == 1
+
+
+def test_vu_colour_helpers_match_the_restatement(cm, oracle):
+    """SURVEY 8f-4 (ref: src/util.c).  Parity unpinned: no reference vectors exist; product and
+    oracle restatement are compared over a grid, plus the values the source text fixes."""
+    import math
+    lib, o = cm.lib, oracle.lib
+    for p in [-200.0, -20.0001, -20.0, -19.9, -10.0, -3.0111266389980154, -1e-9, 0.0, 0.5, -math.inf]:
+        assert lib.coolmic_util_power2hue(p, b"default") == o.oracle_power2hue(p)
+    assert lib.coolmic_util_power2hue(-30.0, b"default") == math.pi * 2 / 3
+    assert lib.coolmic_util_power2hue(-10.0, b"other") == 0.0
+    for pk in [-32768, -32767, -30001, -30000, -28001, -28000, 0, 27999, 28000, 28001, 30000, 30001, 32766, 32767]:
+        assert lib.coolmic_util_peak2hue(pk, b"default") == o.oracle_peak2hue(pk)
+    assert lib.coolmic_util_peak2hue(32767, b"default") == 0.0
+    assert lib.coolmic_util_peak2hue(30001, b"default") == 0.43
+    assert lib.coolmic_util_peak2hue(100, b"default") == math.pi * 2 / 3
+    for a in (0.0, 0.5, 1.0, 2.0):
+        for h in np.linspace(-0.5, 7.0, 61):
+            for sat in (0.0, 0.3, 1.0):
+                for v in (0.0, 0.7, 1.0, 1.5):
+                    assert lib.coolmic_util_ahsv2argb(a, h, sat, v) == o.oracle_ahsv2argb(a, h, sat, v)
+    assert lib.coolmic_util_ahsv2argb(1.0, 0.0, 1.0, 1.0) == 0xFFFF0000          # red
+    assert lib.coolmic_util_ahsv2argb(1.0, math.pi * 2 / 3, 1.0, 1.0) & 0xFF00FF00 == 0xFF00FF00   # green channel full
+    # the batch form
+    res = (cm.VuResult * 3)()
+    res[0].global_power, res[0].global_peak = -30.0, 100
+    res[1].global_power, res[1].global_peak = -3.0, 30500
+    res[2].global_power, res[2].global_peak = 0.0, -32768
+    pw = (C.c_uint32 * 3)()
+    pk = (C.c_uint32 * 3)()
+    lib.coolmic_util_vu_argb(res, 3, b"default", pw, pk)
+    for i in range(3):
+        assert pw[i] == o.oracle_ahsv2argb(1.0, o.oracle_power2hue(res[i].global_power), 1.0, 1.0)
+        assert pk[i] == o.oracle_ahsv2argb(1.0, o.oracle_peak2hue(res[i].global_peak), 1.0, 1.0)
+    assert pk[2] == 0xFFFF0000
