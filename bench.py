@@ -208,6 +208,27 @@ def main():
         except Exception as e:           # measurement extras must not break the line
             extras["ceiling_error"] = str(e)
         out["measured_ceilings"] = extras
+        # the small-block regime, same batch, fewer frames per launch (kernel only)
+        sweep = {}
+        try:
+            for frames in (512, 4096):
+                if frames >= T:
+                    continue
+                b.vu_reset(-1)
+                for _ in range(3):
+                    b.run(frames)
+                b.sync()
+                b.timing(True)
+                b.timing_read()
+                for _ in range(20):
+                    b.run(frames)
+                ms, n = b.timing_read()
+                b.timing(False)
+                sweep[str(frames)] = {"kernel_avg_ms": round(ms / n, 4),
+                                      "achieved_GBs": round(S * Cn * frames * bps / (ms / n * 1e-3) / 1e9, 1)}
+        except Exception as e:
+            sweep["error"] = str(e)
+        out["small_blocks_kernel_only"] = sweep
     b.close()
 
     if rank == 0 and not args.no_extras and not eq:
