@@ -191,8 +191,9 @@ def main():
         "metric": "Msamples/s transform->vumeter", "value": round(value, 1), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "int16 (int32 product, int64 accumulate)"
-        if not eq else "f32",
+        "scaling": "weak", "vs_baseline": None, "dtype": "int16" if not eq else "f32",
+        "arithmetic": "int16 PCM, exact int32 products / division, int64 VU accumulation, dB in f64 on the host"
+        if not eq else "int16 in, exact integer gain, f32 biquads (fixed fmaf order), f32 out",
         "data": "synthetic (per-stream LCG noise generated on device, seed 12345 + stream id)",
         "config": {"workload": "%s: %s" % (args.workload, desc), "streams_per_gpu": S,
                    "channels": Cn, "frames_per_launch": T, "sharding": "stream s -> rank s %% %d" % world,
