@@ -129,6 +129,8 @@ def main():
         torch.cuda.synchronize()
 
     def run_steps(n):
+        # order per step: launch, snapshot of this window (async), then the host finishes the
+        # PREVIOUS window -- the next launch is always queued before the host blocks
         pending = False
         for _ in range(n):
             b.run(T)
@@ -141,9 +143,9 @@ def main():
                 else:
                     shard.combine_node_records(dist, node_words)
             if has_vu:
+                b.vu_snapshot()                      # async D2H of all windows + reset
                 if pending:
                     b.vu_collect(results, rcs)       # dB finish of the previous window (host)
-                b.vu_snapshot()                      # async D2H of all windows + reset
                 pending = True
         if pending:
             b.vu_collect(results, rcs)

@@ -151,11 +151,11 @@ struct cmhip_batch {
     float *d_f32;
     StreamParam *d_param;
     VuState *d_vu;                         // the window runs accumulate into (= d_vu2[cur])
-    VuState *d_vu2[2];                     // two sets: one accumulates while the other is copied out
+    VuState *d_vu2[3];                     // three sets in rotation: accumulating / being copied out / cleared
     unsigned int cur;
     hipStream_t copy_stream;               // snapshots travel here, beside the next run
-    hipEvent_t ev_main, ev_reset[2];
-    bool reset_pending[2];
+    hipEvent_t ev_main, ev_reset[3];
+    bool reset_pending[3];
     struct FinishPool *pool;
     uint32_t *d_nframes;
     EqParam *d_eq;
@@ -172,15 +172,15 @@ struct cmhip_batch {
     unsigned int nsec;
     bool eq_dirty;
 
-    VuState *h_snap;                       // pinned, S entries
+    VuState *h_snap2[2];                   // pinned, S entries each: two snapshots may be in flight
+    hipEvent_t snap_event2[2];
+    unsigned int snap_parity2[2];
+    unsigned int snap_head, snap_count;    // ring of pending snapshots (oldest = head)
     unsigned char *h_stage;                // pinned upload ring, STAGE_SLOTS x STAGE_BYTES
     hipEvent_t stage_ev[4];
     bool stage_busy[4];
     unsigned int stage_next;
-    hipEvent_t snap_event;
-    bool snap_pending;
     unsigned int parity;                   // current slot of VuState::samples
-    unsigned int snap_parity;
 
     bool timing;
     std::vector<EventPair> ev_used, ev_free;
@@ -245,19 +245,20 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
-    if (b->snap_event)
-        (void)hipEventDestroy(b->snap_event);
+    for (int i = 0; i < 2; i++)
+        if (b->snap_event2[i])
+            (void)hipEventDestroy(b->snap_event2[i]);
     if (b->d_out && b->d_out != b->d_in)
         (void)hipFree(b->d_out);
     (void)hipFree(b->d_in);
     (void)hipFree(b->d_f32);
     (void)hipFree(b->d_param);
-    (void)hipFree(b->d_vu2[0]);
-    (void)hipFree(b->d_vu2[1]);
+    for (int i = 0; i < 3; i++)
+        (void)hipFree(b->d_vu2[i]);
     delete b->pool;
     if (b->ev_main)
         (void)hipEventDestroy(b->ev_main);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 3; i++)
         if (b->ev_reset[i])
             (void)hipEventDestroy(b->ev_reset[i]);
     if (b->copy_stream) {
@@ -269,8 +270,9 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     (void)hipFree(b->d_eqstate);
     (void)hipFree(b->d_sink);
     (void)hipFree(b->d_dbg);
-    if (b->h_snap)
-        (void)hipHostFree(b->h_snap);
+    for (int i = 0; i < 2; i++)
+        if (b->h_snap2[i])
+            (void)hipHostFree(b->h_snap2[i]);
     if (b->h_stage)
         (void)hipHostFree(b->h_stage);
     for (unsigned i = 0; i < STAGE_SLOTS; i++)
@@ -311,7 +313,7 @@ static int batch_init(cmhip_batch_t *b)
         HIP_TRY(hipMemsetAsync(b->d_f32, 0, fbytes, b->stream));
     }
     HIP_TRY(hipMalloc((void **)&b->d_param, S * sizeof(StreamParam)));
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         HIP_TRY(hipMalloc((void **)&b->d_vu2[i], S * sizeof(VuState)));
         HIP_TRY(hipMemsetAsync(b->d_vu2[i], 0, S * sizeof(VuState), b->stream));
         HIP_TRY(hipEventCreateWithFlags(&b->ev_reset[i], hipEventDisableTiming));
@@ -331,8 +333,10 @@ static int batch_init(cmhip_batch_t *b)
         HIP_TRY(hipMemsetAsync(b->d_eqstate, 0, S * sizeof(EqState), b->stream));
         b->h_eq.assign(S, EqParam{});
     }
-    HIP_TRY(hipHostMalloc((void **)&b->h_snap, S * sizeof(VuState), hipHostMallocDefault));
-    HIP_TRY(hipEventCreateWithFlags(&b->snap_event, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipHostMalloc((void **)&b->h_snap2[i], S * sizeof(VuState), hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&b->snap_event2[i], hipEventDisableTiming));
+    }
     HIP_TRY(hipHostMalloc((void **)&b->h_stage, STAGE_SLOTS * STAGE_BYTES, hipHostMallocDefault));
     for (unsigned i = 0; i < STAGE_SLOTS; i++)
         HIP_TRY(hipEventCreateWithFlags(&b->stage_ev[i], hipEventDisableTiming));
@@ -385,29 +389,29 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->d_f32 = nullptr;
     b->d_param = nullptr;
     b->d_vu = nullptr;
-    b->d_vu2[0] = b->d_vu2[1] = nullptr;
+    b->d_vu2[0] = b->d_vu2[1] = b->d_vu2[2] = nullptr;
     b->cur = 0;
     b->copy_stream = nullptr;
     b->ev_main = nullptr;
-    b->ev_reset[0] = b->ev_reset[1] = nullptr;
-    b->reset_pending[0] = b->reset_pending[1] = false;
+    b->ev_reset[0] = b->ev_reset[1] = b->ev_reset[2] = nullptr;
+    b->reset_pending[0] = b->reset_pending[1] = b->reset_pending[2] = false;
     b->pool = nullptr;
     b->d_nframes = nullptr;
     b->d_eq = nullptr;
     b->d_eqstate = nullptr;
     b->d_sink = nullptr;
     b->d_dbg = nullptr;
-    b->h_snap = nullptr;
+    b->h_snap2[0] = b->h_snap2[1] = nullptr;
+    b->snap_event2[0] = b->snap_event2[1] = nullptr;
+    b->snap_parity2[0] = b->snap_parity2[1] = 0;
+    b->snap_head = b->snap_count = 0;
     b->h_stage = nullptr;
     for (unsigned i = 0; i < STAGE_SLOTS; i++) {
         b->stage_ev[i] = nullptr;
         b->stage_busy[i] = false;
     }
     b->stage_next = 0;
-    b->snap_event = nullptr;
-    b->snap_pending = false;
     b->parity = 0;
-    b->snap_parity = 0;
     b->param_dirty = true;
     b->all_identity = true;
     b->eq_dirty = false;
@@ -940,29 +944,32 @@ extern "C" int cmhip_batch_vu_snapshot(cmhip_batch_t *b)
         return fail(COOLMIC_ERROR_FAULT, "vu_snapshot: batch is NULL");
     if (!(b->d.flags & CMHIP_VU))
         return fail(COOLMIC_ERROR_INVAL, "vu_snapshot: batch without VU");
-    if (b->snap_pending)
-        return fail(COOLMIC_ERROR_BUSY, "vu_snapshot: previous snapshot not collected");
+    if (b->snap_count == 2)
+        return fail(COOLMIC_ERROR_BUSY, "vu_snapshot: two snapshots are waiting to be collected");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     const size_t bytes = b->d.streams * sizeof(VuState);
-    // The closed windows travel to the host on the copy stream and are cleared there,
-    // while the main stream goes straight on with the next block into the other set.
+    // The closed windows travel to the host on the copy stream and are cleared there, while
+    // the main stream goes straight on with the next block into the next set.  Three sets
+    // rotate so that the set a launch switches to was cleared a whole launch earlier: with
+    // two, every launch waited for the copy + clear that ran beside its predecessor.
     const unsigned i = b->cur;
+    const unsigned slot = (b->snap_head + b->snap_count) & 1u;
     HIP_TRY(hipEventRecord(b->ev_main, b->stream));
     HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_main, 0));
-    HIP_TRY(hipMemcpyAsync(b->h_snap, b->d_vu2[i], bytes, hipMemcpyDeviceToHost, b->copy_stream));
-    HIP_TRY(hipEventRecord(b->snap_event, b->copy_stream));
+    HIP_TRY(hipMemcpyAsync(b->h_snap2[slot], b->d_vu2[i], bytes, hipMemcpyDeviceToHost, b->copy_stream));
+    HIP_TRY(hipEventRecord(b->snap_event2[slot], b->copy_stream));
     HIP_TRY(hipMemsetAsync(b->d_vu2[i], 0, bytes, b->copy_stream));
     HIP_TRY(hipEventRecord(b->ev_reset[i], b->copy_stream));
     b->reset_pending[i] = true;
-    b->cur = i ^ 1u;
+    b->cur = (i + 1u) % 3u;
     b->d_vu = b->d_vu2[b->cur];
     if (b->reset_pending[b->cur]) {          // the set we switch to must have been cleared
         HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_reset[b->cur], 0));
         b->reset_pending[b->cur] = false;
     }
-    b->snap_parity = b->parity;
-    b->snap_pending = true;
+    b->snap_parity2[slot] = b->parity;
+    b->snap_count++;
     return COOLMIC_ERROR_NONE;
 }
 
@@ -970,21 +977,24 @@ extern "C" int cmhip_batch_vu_collect(cmhip_batch_t *b, coolmic_vumeter_result_t
 {
     if (!b || !out)
         return fail(COOLMIC_ERROR_FAULT, "vu_collect: NULL argument");
-    if (!b->snap_pending)
+    if (b->snap_count == 0)
         return fail(COOLMIC_ERROR_INVAL, "vu_collect: no snapshot pending");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
-    HIP_TRY(hipEventSynchronize(b->snap_event));
-    b->snap_pending = false;
+    const unsigned slot = b->snap_head;
+    HIP_TRY(hipEventSynchronize(b->snap_event2[slot]));
+    b->snap_head = (slot + 1u) & 1u;
+    b->snap_count--;
     struct Job {
         cmhip_batch_t *b;
         coolmic_vumeter_result_t *out;
         int *rc;
-    } job = {b, out, rc};
+        unsigned slot;
+    } job = {b, out, rc, slot};
     auto body = [](void *p, unsigned lo, unsigned hi) {
         Job *j = (Job *)p;
         for (unsigned s = lo; s < hi; s++) {
-            const int r = finish_window(j->b, j->b->h_snap[s], j->b->snap_parity, &j->out[s]);
+            const int r = finish_window(j->b, j->b->h_snap2[j->slot][s], j->b->snap_parity2[j->slot], &j->out[s]);
             if (j->rc)
                 j->rc[s] = r;
         }

@@ -522,7 +522,9 @@ def test_batch_api_error_paths(gpu):
     r = (cm.VuResult * 2)()
     assert cm.lib.cmhip_batch_vu_collect(b.h, r, None) == cm.ERROR_INVAL    # no snapshot pending
     b.vu_snapshot()
+    b.vu_snapshot()                                               # two may be in flight
     assert cm.lib.cmhip_batch_vu_snapshot(b.h) == cm.ERROR_BUSY
+    b.vu_collect()
     b.vu_collect()
     assert cm.lib.cmhip_batch_run(None, 1, None) == cm.ERROR_FAULT
     assert b"" != cm.lib.cmhip_last_error()
