@@ -954,13 +954,19 @@ __global__ __launch_bounds__(64) void k_eq(EqArgs a)
 // workgroup takes 16 streams (6 KiB per step) and two workgroups share a CU; the waves are
 // ordered REC, FIR, store, loaders so that the recurrence waves land on their own SIMDs.
 
-constexpr u32 EP_TB = 64;                // frames per block
-constexpr u32 EP_ROW = 68;               // floats per LDS row
 
-template <int NSEC, int G>
-__global__ __launch_bounds__((2 * ((NSEC + 64 / G - 1) / (64 / G)) + 1 + G / 8) * 64)
+// TB = frames per block (64 or 128): bigger blocks amortise the barrier and the LDS latency
+// after it, at twice the LDS footprint.
+template <int NSEC, int G, int TB>
+__global__ __launch_bounds__((2 * ((NSEC + 64 / G - 1) / (64 / G)) + 1 + G / (512 / TB)) * 64)
 void k_eq_pipe(EqArgs a)
 {
+    constexpr u32 EP_TB = TB;                     // frames per block
+    constexpr u32 EP_ROW = TB + 4;                // floats per LDS row (16-byte aligned, conflict free)
+    constexpr u32 LPR = TB / 8;                   // loader lanes per row (8 frames each)
+    constexpr u32 RPW = 64 / LPR;                 // rows one loader wave covers
+    constexpr u32 SPR = TB / 4;                   // store lanes per row (4 frames each)
+    constexpr u32 RPI = 64 / SPR;                 // rows per store instruction
     constexpr u32 EP_G = G;
     constexpr u32 EP_TILE = EP_G * EP_ROW;        // floats per buffer slot
     constexpr u32 SPW = 64 / G;                   // sections per FIR / REC wave
@@ -976,7 +982,7 @@ void k_eq_pipe(EqArgs a)
     const bool is_fir = wave >= NSW && wave < 2 * NSW;
     const bool is_store = wave == 2 * NSW;
     const bool is_loader = wave > 2 * NSW;
-    const u32 lw = wave - 2 * NSW - 1u;                   // loader index 0..G/8-1
+    const u32 lw = wave - 2 * NSW - 1u;                   // loader index 0..G/RPW-1
     const u32 sec = (is_rec ? wave : wave - NSW) * SPW + lane / EP_G;   // section of this lane
     const bool has_sec = (is_rec || is_fir) && sec < (u32)NSEC;
 
@@ -996,8 +1002,8 @@ void k_eq_pipe(EqArgs a)
     __syncthreads();
 
     // loaders: lane handles stream r = 8*lw + lane/8, frames (lane%8)*8 .. +7 of each block
-    const u32 l_r = 8u * lw + (lane >> 3);
-    const u32 l_t8 = (lane & 7u) * 8u;
+    const u32 l_r = RPW * lw + lane / LPR;
+    const u32 l_t8 = (lane % LPR) * 8u;
     u32 l_magic = 0, l_shift = 0, l_g2 = 0, l_n = 0;
     if (is_loader) {
         const u32 sr = min(s0 + l_r, a.streams - 1);
@@ -1156,9 +1162,9 @@ void k_eq_pipe(EqArgs a)
                 const u32 b = step - stage;
                 const float *Y = lds + ((u32)(2 * NSEC) * 2u + (b & 1u)) * EP_TILE;
 #pragma unroll
-                for (u32 i = 0; i < EP_G / 4; i++) {
-                    const u32 r = 4u * i + (lane >> 4);
-                    const u32 t4 = (lane & 15u) * 4u;
+                for (u32 i = 0; i < EP_G / RPI; i++) {
+                    const u32 r = RPI * i + lane / SPR;
+                    const u32 t4 = (lane % SPR) * 4u;
                     const u32 f0 = b * EP_TB + t4;
                     const u32 n = nfr_lds[r];
                     const float4 v = *reinterpret_cast<const float4 *>(Y + r * EP_ROW + t4);
@@ -1202,37 +1208,47 @@ void k_eq_pipe(EqArgs a)
     (void)is_store;
 }
 
-template <int NSEC, int G>
+template <int NSEC, int G, int TB>
 static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
 {
-    const size_t lds_bytes = ((size_t)(2 * NSEC + 1) * 2 * G * EP_ROW) * sizeof(float) + G * sizeof(u32);
+    const size_t lds_bytes = ((size_t)(2 * NSEC + 1) * 2 * G * (TB + 4)) * sizeof(float) + G * sizeof(u32);
+    if (lds_bytes > 160 * 1024)
+        return hipErrorInvalidValue;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G, TB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess)
             return e;
         configured = true;
     }
     constexpr int SPW = 64 / G, NSW = (NSEC + SPW - 1) / SPW;
-    hipLaunchKernelGGL((k_eq_pipe<NSEC, G>), dim3((a.streams + G - 1) / G), dim3((2 * NSW + 1 + G / 8) * 64),
-                       lds_bytes, st, a);
+    hipLaunchKernelGGL((k_eq_pipe<NSEC, G, TB>), dim3((a.streams + G - 1) / G),
+                       dim3((2 * NSW + 1 + G / (512 / TB)) * 64), lds_bytes, st, a);
     return hipGetLastError();
 }
 
 template <int NSEC>
 static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st)
 {
-    const char *e = getenv("CMHIP_EQ_G");                 // tuning knob
-    int g = e ? atoi(e) : 32;                             // 32: best on MI355X
-    // the tiles of a 32-stream workgroup must fit the 160 KiB of LDS
-    if (g == 32 && ((size_t)(2 * NSEC + 1) * 2 * 32 * EP_ROW) * sizeof(float) + 32 * sizeof(u32) > 160 * 1024)
+    const char *e = getenv("CMHIP_EQ_G");                 // tuning knobs
+    const char *t = getenv("CMHIP_EQ_TB");
+    int g = e ? atoi(e) : 32;                             // 32 x 64: best on MI355X
+    const int tb = t ? atoi(t) : 64;
+    // the tiles of a workgroup must fit the 160 KiB of LDS
+    auto fits = [&](int gg) { return ((size_t)(2 * NSEC + 1) * 2 * gg * (tb + 4)) * sizeof(float) + gg * sizeof(u32) <= 160 * 1024; };
+    if (g == 32 && !fits(32))
         g = 16;
-    if (g == 32)
-        return launch_eq_pipe<NSEC, 32>(a, st);
-    if (g == 16)
-        return launch_eq_pipe<NSEC, 16>(a, st);
-    return launch_eq_pipe<NSEC, 8>(a, st);
+    if (g == 16 && !fits(16))
+        g = 8;
+    if (tb == 128) {
+        if (g == 32) return launch_eq_pipe<NSEC, 32, 128>(a, st);
+        if (g == 16) return launch_eq_pipe<NSEC, 16, 128>(a, st);
+        return launch_eq_pipe<NSEC, 8, 128>(a, st);
+    }
+    if (g == 32) return launch_eq_pipe<NSEC, 32, 64>(a, st);
+    if (g == 16) return launch_eq_pipe<NSEC, 16, 64>(a, st);
+    return launch_eq_pipe<NSEC, 8, 64>(a, st);
 }
 
 hipError_t launch_eq(const EqArgs &a, hipStream_t st)
