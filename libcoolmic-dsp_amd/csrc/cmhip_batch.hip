@@ -211,7 +211,10 @@ static void rebuild_param(cmhip_batch_t *b, unsigned int s)
 {
     StreamParam &p = b->h_param[s];
     const uint16_t scale = b->h_scale[s];
-    if (scale == 0) {                       // disabled: identity through the same arithmetic
+    bool unity = scale != 0;                // trunc(x * g / g) == x: same as disabled
+    for (unsigned c = 0; unity && c < b->d.channels; c++)
+        unity = b->h_gain[(size_t)s * MAX_CH + c] == scale;
+    if (scale == 0 || unity) {              // disabled: identity through the same arithmetic
         host_magic(1, &p.magic, &p.shift);
         for (unsigned c = 0; c < MAX_CH; c++)
             p.gain2[c] = 2u;

@@ -184,6 +184,13 @@ __device__ __forceinline__ int gain1(int x, u32 g2, u32 magic, u32 shift, u32 &m
     return (int)((mag ^ (u32)sg) - (u32)sg);
 }
 
+// value of another lane by DPP (0 where the source lane is outside the row)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
 // wave64 reductions on the VALU (DPP), result valid in lane 63
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ u32 dpp0(u32 v)       // lanes without a source read 0
@@ -931,324 +938,487 @@ __global__ __launch_bounds__(64) void k_eq(EqArgs a)
 // ---------------------------------------------------------------------------
 // Pipelined EQ (float output only, 1..4 sections): the fast form of config 3.
 //
-// The recurrence allows no parallelism along time, and what limits a wave that walks a
-// stream is its own issue rate (one VALU op per ~4-5 cycles when it is the only ready wave
-// of its SIMD).  So the per-sample work is cut into pipeline stages that run in different
-// waves of a workgroup, connected by double-buffered LDS tiles, one __syncthreads() per
-// 64-frame block:
+// The recurrence allows no parallelism along time, so the per-sample work is cut in two:
 //
-//   loaders  global load (next block prefetched), gain, int16 -> float        -> X
-//   FIR_k    f[t] = fma(b2, x[t-2], fma(b1, x[t-1], b0*x[t]))   (3 ops/sample)  -> F_k
-//   REC_k    y[t] = fma(-a1, y[t-1], fma(-a2, y[t-2], f[t]))    (2 ops/sample)  -> Y_k
-//   store    coalesced non-temporal stores of Y_last
+//   feed-forward  f[t] = fma(b2, x[t-2], fma(b1, x[t-1], b0*x[t]))      no loop-carried dependence
+//   recurrence    y[t] = fma(-a1, y[t-1], fma(-a2, y[t-2], f[t]))       two dependent FMAs
 //
-// This is the oracle's Direct Form I evaluated in the same order, only cut in two: the
-// feed-forward half has no loop-carried dependence, the recurrence keeps just the two
-// dependent FMAs.  A FIR wave and a REC wave each carry 64/G sections side by side in
-// their lanes (lane = section * G + stream), every lane group one stage behind the
-// previous one, so one instruction stream serves the whole cascade.  Rows are 68 floats:
-// 16-byte aligned and conflict-free for lane-per-row b128 access, also across lane groups
-// (tile sizes are multiples of 64 floats).
+// which is the oracle's Direct Form I in the same operation order.  A workgroup owns G
+// streams and walks them in 64-frame blocks, one __syncthreads() per block, with two kinds
+// of waves that hand 64-frame rows to each other through double-buffered LDS tiles:
 //
-// Sizing notes from stage ablation on MI355X: a CU moves ~10 B/clk of global traffic, so a
-// workgroup takes 16 streams (6 KiB per step) and two workgroups share a CU; the waves are
-// ordered REC, FIR, store, loaders so that the recurrence waves land on their own SIMDs.
+//   T waves (lane = stream row x 8-frame chunk; time-parallel, G/8 of them):
+//     global load (two blocks ahead) -> gain -> float -> feed-forward of section 0 -> F_0
+//     Y_k-1 -> feed-forward of section k -> F_k               (k = 1 .. NSEC-1)
+//     Y_last -> coalesced non-temporal global stores
+//     x[t-1], x[t-2] of a chunk come from the neighbouring lane by DPP (row_shr:1), those
+//     of a block's first chunk from the last chunk of the previous step (row_shl:7).
+//   R waves (lane = section x stream; 64/G sections side by side, sequential in time):
+//     F_k -> the two dependent FMAs per sample -> Y_k
+//
+// Measured on MI355X (tools/ubench_chain.hip, ubench_lds*.hip): a wave alone issues one
+// VALU op per ~4.3 clk, a dependent one after ~8; ds_read_b128 costs a wave ~5-10 clk to
+// issue, ds_write_b128 ~24 (50 when four waves write at once).  So the only waves that are
+// long per step are the R waves (16 reads, 128 FMAs, 16 writes); everything without a
+// recurrence is spread over T lanes, where a 64-frame row costs 2 reads + 2 writes.
+// Rows are 68 floats (16-byte aligned, lane-per-row b128 access without bank conflicts).
 
+#ifndef CMHIP_EQ_RLAG
+#define CMHIP_EQ_RLAG 1           // R waves load the next row into registers a step ahead (0: same step)
+#endif
+#ifndef CMHIP_EQ_ABL
+#define CMHIP_EQ_ABL 0            // `make abl`: timing-only builds with one part of the pipeline cut out
+#endif
 
-// TB = frames per block (64 or 128): bigger blocks amortise the barrier and the LDS latency
-// after it, at twice the LDS footprint.
-template <int NSEC, int G, int TB>
-__global__ __launch_bounds__((2 * ((NSEC + 64 / G - 1) / (64 / G)) + 1 + G / (512 / TB)) * 64)
+template <int NSEC, int G>
+__global__ __launch_bounds__((((NSEC + 64 / G - 1) / (64 / G)) + G / 8 + 1) * 64)
 void k_eq_pipe(EqArgs a)
 {
-    constexpr u32 EP_TB = TB;                     // frames per block
-    constexpr u32 EP_ROW = TB + 4;                // floats per LDS row (16-byte aligned, conflict free)
-    constexpr u32 LPR = TB / 8;                   // loader lanes per row (8 frames each)
-    constexpr u32 RPW = 64 / LPR;                 // rows one loader wave covers
-    constexpr u32 SPR = TB / 4;                   // store lanes per row (4 frames each)
+    constexpr u32 EP_TB = 64;                     // frames per block
+    constexpr u32 EP_ROW = EP_TB + 4;             // floats per LDS row
+    constexpr u32 EP_TILE = G * EP_ROW;           // floats per buffer slot
+    constexpr u32 SPW = 64 / G;                   // sections per R wave
+    constexpr u32 NRW = (NSEC + SPW - 1) / SPW;   // R waves
+    constexpr u32 NTW = G / 8;                    // T waves: 8 rows x 8 chunks each
+    constexpr u32 NBUF = 2 * NSEC;                // F_0, Y_0, F_1, Y_1, ...
+    constexpr u32 SPR = EP_TB / 4;                // store lanes per row (4 frames each)
     constexpr u32 RPI = 64 / SPR;                 // rows per store instruction
-    constexpr u32 EP_G = G;
-    constexpr u32 EP_TILE = EP_G * EP_ROW;        // floats per buffer slot
-    constexpr u32 SPW = 64 / G;                   // sections per FIR / REC wave
-    constexpr u32 NSW = (NSEC + SPW - 1) / SPW;   // FIR waves = REC waves
-    constexpr u32 NBUF = 2 * NSEC + 1;            // X, F_0, Y_0, F_1, Y_1, ...
+    constexpr int DPP_SHR1 = 0x111, DPP_SHL7 = 0x107;
+    constexpr u32 HOP = CMHIP_EQ_RLAG ? 3 : 2;     // steps from F_k to F_k+1
     extern __shared__ float lds[];                // NBUF buffers x 2 slots x EP_TILE floats, then G counts
     u32 *nfr_lds = reinterpret_cast<u32 *>(lds + NBUF * 2 * EP_TILE);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const u32 s0 = blockIdx.x * EP_G;
+    const u32 s0 = blockIdx.x * G;
 
-    // roles by wave index
-    const bool is_rec = wave < NSW;
-    const bool is_fir = wave >= NSW && wave < 2 * NSW;
-    const bool is_store = wave == 2 * NSW;
-    const bool is_loader = wave > 2 * NSW;
-    const u32 lw = wave - 2 * NSW - 1u;                   // loader index 0..G/RPW-1
-    const u32 sec = (is_rec ? wave : wave - NSW) * SPW + lane / EP_G;   // section of this lane
-    const bool has_sec = (is_rec || is_fir) && sec < (u32)NSEC;
+    const bool is_rec = wave < NRW;
+    const bool is_store = wave == NRW + NTW;              // the S wave
+    const u32 tw = wave - NRW;                            // T wave index
 
-    // frame counts of the G streams; lane groups beyond the first mirror it
-    const u32 row = lane % EP_G;
+    // R lanes: section and stream row
+    const u32 sec = wave * SPW + lane / G;
+    const bool has_sec = is_rec && sec < (u32)NSEC;
+    const u32 row = lane % G;
     const u32 sl = s0 + row;
     const bool live = sl < a.streams;
     const u32 my_nfr = live ? (a.nframes ? a.nframes[sl] : a.frames) : 0u;
-    if (wave == 0 && lane < EP_G)
+    if (wave == 0 && lane < G)
         nfr_lds[lane] = my_nfr;
     u32 nmax = my_nfr;
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1)
         nmax = max(nmax, (u32)__shfl_xor((int)nmax, o, 64));
     const u32 nblocks = (nmax + EP_TB - 1) / EP_TB;
-    const u32 nsteps = nblocks + 2 * NSEC + 1;
+    const u32 nsteps = nblocks + HOP * NSEC;
     __syncthreads();
 
-    // loaders: lane handles stream r = 8*lw + lane/8, frames (lane%8)*8 .. +7 of each block
-    const u32 l_r = RPW * lw + lane / LPR;
-    const u32 l_t8 = (lane % LPR) * 8u;
-    u32 l_magic = 0, l_shift = 0, l_g2 = 0, l_n = 0;
-    if (is_loader) {
-        const u32 sr = min(s0 + l_r, a.streams - 1);
-        l_magic = a.param[sr].magic;
-        l_shift = a.param[sr].shift;
-        l_g2 = a.param[sr].gain2[0];
-        l_n = nfr_lds[l_r];
-    }
-    // FIR lanes own x1,x2 of their section, REC lanes own y1,y2 (EqState: x1 x2 y1 y2)
-    float c0 = 0, c1 = 0, c2 = 0, h1 = 0, h2 = 0;
+    // R lanes own y1, y2 of their section (EqState: x1 x2 y1 y2)
+    float d1 = 0, d2 = 0, h1 = 0, h2 = 0;
     if (has_sec && live) {
         const float *c = a.eq[sl].coef[sec];
         const float *st = a.state[sl].s[sec];
-        if (is_fir) {
-            // section 0 sees integer-valued samples (see the loaders): fold the 2^-15 in here.
-            // Its history is kept in the same unscaled form inside the kernel and converted
-            // at the EqState boundary, so the state stays what the oracle's would be.
-            const float k = sec == 0 ? (1.0f / 32768.0f) : 1.0f;
-            const float ki = sec == 0 ? 32768.0f : 1.0f;
-            c0 = c[0] * k; c1 = c[1] * k; c2 = c[2] * k;
-            h1 = st[0] * ki; h2 = st[1] * ki;
-        } else {
-            c1 = -c[3]; c2 = -c[4];
-            h1 = st[2]; h2 = st[3];
+        d1 = -c[3]; d2 = -c[4];
+        h1 = st[2]; h2 = st[3];
+    }
+
+    // T lanes: stream row l_r, frames l_t8 .. l_t8+7 of every block
+    const u32 l_r = 8u * tw + lane / 8u;
+    const u32 l_c = lane % 8u;
+    const u32 l_t8 = l_c * 8u;
+    const u32 l_s = min(s0 + l_r, a.streams - 1);
+    const bool l_live = !is_rec && !is_store && s0 + l_r < a.streams;
+    u32 l_magic = 0, l_shift = 0, l_g2 = 0, l_n = 0;
+    float fc[NSEC][3];                                    // b0 b1 b2 of every section of this row
+    float sx1[NSEC], sx2[NSEC];                           // x[t-1], x[t-2] before the next block
+#pragma unroll
+    for (int k = 0; k < NSEC; k++) {
+        fc[k][0] = fc[k][1] = fc[k][2] = 0.f;
+        sx1[k] = sx2[k] = 0.f;
+    }
+    if (!is_rec && !is_store) {
+        l_magic = a.param[l_s].magic;
+        l_shift = a.param[l_s].shift;
+        l_g2 = a.param[l_s].gain2[0];
+        l_n = nfr_lds[l_r];
+        if (l_live) {
+#pragma unroll
+            for (int k = 0; k < NSEC; k++) {
+                // section 0 sees integer-valued samples (the 2^-15 of "x / 32768.f" is not
+                // applied by the conversion): it is folded into the coefficients instead, which
+                // is bit-identical because power-of-two scaling commutes with every rounding
+                // of the chain.  Its history is kept in the same unscaled form inside the
+                // kernel and converted at the EqState boundary.
+                const float sc = k == 0 ? (1.0f / 32768.0f) : 1.0f;
+                const float si = k == 0 ? 32768.0f : 1.0f;
+                const float *c = a.eq[l_s].coef[k];
+                const float *st = a.state[l_s].s[k];
+                fc[k][0] = c[0] * sc; fc[k][1] = c[1] * sc; fc[k][2] = c[2] * sc;
+                sx1[k] = st[0] * si; sx2[k] = st[1] * si;
+            }
         }
     }
 
-    // loaders keep the NEXT block's PCM in flight while the pipeline works on this one:
-    // the HBM latency of a block is hidden behind a whole pipeline step
-    u32x4 wn = {0, 0, 0, 0};
-    auto fetch = [&](u32 b) {
+    // gain disabled (scale 0, or every gain equal to the scale) is stored as 1/1: x -> x
+    const bool gain_off = __all(l_g2 == 2u && l_shift == 0u);
+
+    // The T waves keep two blocks of PCM in flight: a block's HBM latency is hidden behind
+    // two pipeline steps.  The load is unconditional (address clamped into the stream's own
+    // row, which is a multiple of 8 samples long) and nothing else in a T wave touches
+    // global memory inside the loop, so the compiler can wait with vmcnt(1) for the older
+    // block instead of draining the queue; the stores have a wave of their own.
+    const int16_t *l_src = a.in + (u64)l_s * a.stride;
+    const u32 l_last = (u32)a.stride - 8u;
+    auto fetch = [&](u32 b) -> u32x4 {
         const u32 f0 = b * EP_TB + l_t8;
-        const int16_t *src = a.in + (u64)(s0 + l_r) * a.stride + f0;
-        u32x4 v = {0, 0, 0, 0};
-        if (f0 + 8u <= l_n)                               // whole vectors only; a ragged end is
-            v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src));   // read when consumed
-        wn = v;
+        if (CMHIP_EQ_ABL & 2)
+            return u32x4{f0, f0 * 3u, f0 * 5u, f0 * 7u};
+        return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(l_src + min(f0, l_last)));
     };
-    if (is_loader && nblocks)
-        fetch(0);
+    u32x4 wa = {0, 0, 0, 0}, wb = {0, 0, 0, 0};           // blocks of even / odd steps
+    if (!is_rec && !is_store) {
+        wa = fetch(0);
+        wb = fetch(1);
+    }
+
+    // feed-forward half of section k on the 8 samples of this lane; the two samples before
+    // them come from the lane to the left, or (first chunk) from the end of the last block
+    auto feed_forward = [&](const int k, const float (&x)[8], float (&f)[8]) {
+        const float p1 = dpp_f32<DPP_SHR1>(x[7]), p2 = dpp_f32<DPP_SHR1>(x[6]);
+        const float q1 = dpp_f32<DPP_SHL7>(sx1[k]), q2 = dpp_f32<DPP_SHL7>(sx2[k]);
+        const float xm1 = l_c == 0 ? q1 : p1;
+        const float xm2 = l_c == 0 ? q2 : p2;
+        sx1[k] = x[7];
+        sx2[k] = x[6];
+        const float c0 = fc[k][0], c1 = fc[k][1], c2 = fc[k][2];
+        f[0] = __builtin_fmaf(c2, xm2, __builtin_fmaf(c1, xm1, c0 * x[0]));
+        f[1] = __builtin_fmaf(c2, xm1, __builtin_fmaf(c1, x[0], c0 * x[1]));
+#pragma unroll
+        for (int j = 2; j < 8; j++)
+            f[j] = __builtin_fmaf(c2, x[j - 2], __builtin_fmaf(c1, x[j - 1], c0 * x[j]));
+    };
 
 #ifdef CMHIP_EQ_STAMPS
-    u64 st_busy = 0, st_read = 0;
+    u64 st_busy = 0, st_p[3] = {0, 0, 0};
     const u64 st_begin = __builtin_readcyclecounter();
 #endif
-    for (u32 step = 0; step < nsteps; step++) {
-#ifdef CMHIP_EQ_STAMPS
-        const u64 st_t0 = __builtin_readcyclecounter();
-#endif
-        if (is_loader) {
-            const u32 b = step;
-            if (b < nblocks) {
-                float *X = lds + (b & 1u) * EP_TILE;
-                u32 w[4] = {wn.x, wn.y, wn.z, wn.w};
-                if (b + 1 < nblocks)
-                    fetch(b + 1);
-                const u32 f0 = b * EP_TB + l_t8;
-                if (f0 < l_n && f0 + 8u > l_n) {          // ragged end of this stream (rare)
-                    const int16_t *src = a.in + (u64)(s0 + l_r) * a.stride + f0;
-                    for (u32 j = 0; j < l_n - f0; j++) {
-                        const u32 val = (u32)(uint16_t)src[j];
-#pragma unroll
-                        for (u32 q = 0; q < 4; q++)
-                            if (q == (j >> 1))
-                                w[q] |= val << (16u * (j & 1u));
-                    }
-                }
-                // gain in integers (exact), then straight to float: the magnitude is converted,
-                // the sign bit of the sample is copied in, and one med3 is the int16 saturation.
-                // The 2^-15 of "x / 32768.f" is NOT applied here: section 0 uses coefficients
-                // scaled by 2^-15 instead, which is bit-identical (power-of-two scaling commutes
-                // with every rounding in the chain) and saves a multiply per sample.
-                float f[8];
-#pragma unroll
-                for (u32 q = 0; q < 4; q++) {
-                    const u32 sg = pk_sign(w[q]);
-                    const u32 aw = pk_sub(w[q] ^ sg, sg);
-                    const u32 n0 = __umul24(aw & 0xffffu, l_g2);
-                    const u32 n1 = __umul24(aw >> 16, l_g2);
-                    const float m0 = (float)(__umulhi(n0, l_magic) >> l_shift);
-                    const float m1 = (float)(__umulhi(n1, l_magic) >> l_shift);
-                    const u32 b0 = (__builtin_bit_cast(u32, m0) & 0x7fffffffu) | ((w[q] << 16) & 0x80000000u);
-                    const u32 b1 = (__builtin_bit_cast(u32, m1) & 0x7fffffffu) | (w[q] & 0x80000000u);
-                    f[2 * q] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, b0), -32768.0f, 32767.0f);
-                    f[2 * q + 1] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, b1), -32768.0f, 32767.0f);
-                }
-                float4 *dstx = reinterpret_cast<float4 *>(X + l_r * EP_ROW + l_t8);
-                dstx[0] = make_float4(f[0], f[1], f[2], f[3]);
-                dstx[1] = make_float4(f[4], f[5], f[6], f[7]);
-            }
-        } else if (is_rec || is_fir) {
-            // every lane group runs the same code on its own section, one stage apart
-            const u32 inbuf = 2u * sec + (is_rec ? 1u : 0u);
-            const u32 stage = inbuf + 1u;
-            const bool act = has_sec && step >= stage && step - stage < nblocks;
-            if (act) {
-                const u32 b = step - stage;
-                const float *in = lds + (inbuf * 2u + (b & 1u)) * EP_TILE + row * EP_ROW;
-                float *out = lds + ((inbuf + 1u) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW;
-                const u32 done = b * EP_TB;
-                const u32 cnt = my_nfr > done ? min(my_nfr - done, EP_TB) : 0u;
-                if (__all(cnt == EP_TB)) {
-                    // whole row into registers first: 16 LDS reads in flight at once
-                    float4 v[EP_TB / 4];
+    // Schedule (HOP = 3): F_k of block b is written in step b+3k, loaded into the R lanes'
+    // registers in step b+3k+1 while they still work on block b-1, turned into Y_k in step
+    // b+3k+2, and the block leaves in step b+3*NSEC.  Every buffer is read one step after it
+    // was written, so two slots per buffer are enough (the third copy is in VGPRs).
+    auto rec_step = [&](float4 (&v)[EP_TB / 4], float4 (&nxt)[EP_TB / 4], const u32 step) {
+        if (!(CMHIP_EQ_ABL & 32)) {
+            const u32 first = HOP * sec + HOP - 1u;       // step in which block 0 is worked on
+            const u32 b = step - first;
+            if (CMHIP_EQ_RLAG) {                          // next block's row: into registers now
+                const u32 bp = b + 1u;
+                if (has_sec && step + 1u >= first && bp < nblocks) {
+                    const float4 *in = reinterpret_cast<const float4 *>(
+                        lds + ((2u * sec) * 2u + (bp & 1u)) * EP_TILE + row * EP_ROW);
 #pragma unroll
                     for (u32 t = 0; t < EP_TB / 4; t++)
-                        v[t] = reinterpret_cast<const float4 *>(in)[t];
-#ifdef CMHIP_EQ_STAMPS
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    st_read += __builtin_readcyclecounter() - st_t0;
-#endif
-                    if (is_fir) {
-#pragma unroll
-                        for (u32 t = 0; t < EP_TB / 4; t++) {
-                            float4 f;
-                            f.x = __builtin_fmaf(c2, h2, __builtin_fmaf(c1, h1, c0 * v[t].x));
-                            f.y = __builtin_fmaf(c2, h1, __builtin_fmaf(c1, v[t].x, c0 * v[t].y));
-                            f.z = __builtin_fmaf(c2, v[t].x, __builtin_fmaf(c1, v[t].y, c0 * v[t].z));
-                            f.w = __builtin_fmaf(c2, v[t].y, __builtin_fmaf(c1, v[t].z, c0 * v[t].w));
-                            h2 = v[t].z;
-                            h1 = v[t].w;
-                            reinterpret_cast<float4 *>(out)[t] = f;
-                        }
-                    } else {
-#pragma unroll
-                        for (u32 t = 0; t < EP_TB / 4; t++) {
-                            float4 y;
-                            y.x = __builtin_fmaf(c1, h1, __builtin_fmaf(c2, h2, v[t].x));
-                            y.y = __builtin_fmaf(c1, y.x, __builtin_fmaf(c2, h1, v[t].y));
-                            y.z = __builtin_fmaf(c1, y.y, __builtin_fmaf(c2, y.x, v[t].z));
-                            y.w = __builtin_fmaf(c1, y.z, __builtin_fmaf(c2, y.y, v[t].w));
-                            h2 = y.z;
-                            h1 = y.w;
-                            reinterpret_cast<float4 *>(out)[t] = y;
-                        }
-                    }
-                } else {                                 // some stream ends inside this block
-                    for (u32 t = 0; t < EP_TB; t++) {
-                        const float x0 = in[t];
-                        float r;
-                        if (is_fir)
-                            r = __builtin_fmaf(c2, h2, __builtin_fmaf(c1, h1, c0 * x0));
-                        else
-                            r = __builtin_fmaf(c1, h1, __builtin_fmaf(c2, h2, x0));
-                        if (t < cnt) {                   // history moves only on real samples
-                            h2 = h1;
-                            h1 = is_fir ? x0 : r;
-                        }
-                        out[t] = r;
-                    }
+                        nxt[t] = in[t];
                 }
             }
-        } else {
-            const u32 stage = 2 * NSEC + 1;
-            if (step >= stage && step - stage < nblocks) {
-                const u32 b = step - stage;
-                const float *Y = lds + ((u32)(2 * NSEC) * 2u + (b & 1u)) * EP_TILE;
+            if (has_sec && step >= first && b < nblocks) {
+                float4 *out = reinterpret_cast<float4 *>(
+                    lds + ((2u * sec + 1u) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW);
+                if (!CMHIP_EQ_RLAG) {
+                    const float4 *in = reinterpret_cast<const float4 *>(
+                        lds + ((2u * sec) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW);
 #pragma unroll
-                for (u32 i = 0; i < EP_G / RPI; i++) {
-                    const u32 r = RPI * i + lane / SPR;
-                    const u32 t4 = (lane % SPR) * 4u;
-                    const u32 f0 = b * EP_TB + t4;
-                    const u32 n = nfr_lds[r];
-                    const float4 v = *reinterpret_cast<const float4 *>(Y + r * EP_ROW + t4);
-                    float *dstf = a.f32 + (u64)(s0 + r) * a.plane + f0;
-                    if (f0 + 4u <= n) {
-                        typedef float f32x4 __attribute__((ext_vector_type(4)));
-                        const f32x4 vv = {v.x, v.y, v.z, v.w};
-                        __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(dstf));
-                    } else if (f0 < n) {
-                        const float e[4] = {v.x, v.y, v.z, v.w};
-                        for (u32 j = 0; j < n - f0; j++)
-                            dstf[j] = e[j];
+                    for (u32 t = 0; t < EP_TB / 4; t++)  // whole row first: 16 LDS reads in flight
+                        v[t] = in[t];
+                }
+                const u32 done = b * EP_TB;
+                const u32 cnt = my_nfr > done ? min(my_nfr - done, EP_TB) : 0u;
+                if (CMHIP_EQ_ABL & 4) {
+#pragma unroll
+                    for (u32 t = 0; t < EP_TB / 4; t++)
+                        out[t] = v[t];
+                } else if (__all(cnt == EP_TB)) {
+#pragma unroll
+                    for (u32 t = 0; t < EP_TB / 4; t++) {
+                        float4 y;
+                        y.x = __builtin_fmaf(d1, h1, __builtin_fmaf(d2, h2, v[t].x));
+                        y.y = __builtin_fmaf(d1, y.x, __builtin_fmaf(d2, h1, v[t].y));
+                        y.z = __builtin_fmaf(d1, y.y, __builtin_fmaf(d2, y.x, v[t].z));
+                        y.w = __builtin_fmaf(d1, y.z, __builtin_fmaf(d2, y.y, v[t].w));
+                        h2 = y.z;
+                        h1 = y.w;
+                        if (!(CMHIP_EQ_ABL & 8) || t == 0)
+                            out[t] = y;
+                    }
+                } else {
+                    // some stream ends inside this block: same arithmetic, but the history of a
+                    // lane moves only on its real samples (what lies beyond is never stored)
+#pragma unroll
+                    for (u32 t = 0; t < EP_TB / 4; t++) {
+                        const float xs[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+                        float rs[4];
+#pragma unroll
+                        for (u32 j = 0; j < 4; j++) {
+                            const float r = __builtin_fmaf(d1, h1, __builtin_fmaf(d2, h2, xs[j]));
+                            const bool real = 4u * t + j < cnt;
+                            h2 = real ? h1 : h2;
+                            h1 = real ? r : h1;
+                            rs[j] = r;
+                        }
+                        out[t] = make_float4(rs[0], rs[1], rs[2], rs[3]);
                     }
                 }
             }
         }
+    };
+    float keep1 = 0.f, keep2 = 0.f;                       // section 0's new x1 / x2, if seen
+    bool has1 = false, has2 = false;
+    auto t_step = [&](u32x4 &wcur, const u32 step) {
+        if (!(CMHIP_EQ_ABL & 128)) {
 #ifdef CMHIP_EQ_STAMPS
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        st_busy += __builtin_readcyclecounter() - st_t0;
+            const u64 st_tt = __builtin_readcyclecounter();
 #endif
-        __syncthreads();
+            // rows of the later sections first: their LDS latency passes behind the conversion
+            float4 yin[NSEC][2];
+#pragma unroll
+            for (int k = 1; k < NSEC; k++) {
+                const u32 b = step - HOP * (u32)k;
+                yin[k][0] = yin[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(CMHIP_EQ_ABL & 16) && step >= HOP * (u32)k && b < nblocks) {
+                    const float4 *src = reinterpret_cast<const float4 *>(
+                        lds + ((2u * k - 1u) * 2u + (b & 1u)) * EP_TILE + l_r * EP_ROW + l_t8);
+                    yin[k][0] = src[0];
+                    yin[k][1] = src[1];
+                }
+            }
+            // --- input block `step`: PCM -> gain -> float -> feed-forward of section 0 -> F_0
+            // (also in the drain steps at the end, where it works on zeros: keeping the load
+            // unconditional is what lets the wait above be counted)
+            if (!(CMHIP_EQ_ABL & 64)) {
+                const u32 b = step;
+                const u32 f0 = b * EP_TB + l_t8;
+                const bool have = f0 < l_n;               // beyond the end of the stream: zeros
+                const u32 w[4] = {have ? wcur.x : 0u, have ? wcur.y : 0u, have ? wcur.z : 0u,
+                                  have ? wcur.w : 0u};    // (a chunk the stream ends in keeps what
+                wcur = fetch(b + 2);                      // follows in the row: never stored)
+#ifdef CMHIP_EQ_STAMPS
+                u32 stw = w[0];
+                asm volatile("" : "+v"(stw));
+                st_p[0] += __builtin_readcyclecounter() - st_tt;          // PCM of this block has arrived
+#endif
+                // gain in integers (exact), then straight to float: the magnitude is converted,
+                // the sign bit of the sample is copied in, and one med3 is the int16 saturation
+                float x[8], f[8];
+                if (gain_off) {                           // no master gain on any row of this wave
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) {
+                        x[2 * q] = (float)(int)(int16_t)(w[q] & 0xffffu);
+                        x[2 * q + 1] = (float)((int)w[q] >> 16);
+                    }
+                } else {
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) {
+                        const u32 sg = pk_sign(w[q]);
+                        const u32 aw = pk_sub(w[q] ^ sg, sg);
+                        const u32 n0 = __umul24(aw & 0xffffu, l_g2);
+                        const u32 n1 = __umul24(aw >> 16, l_g2);
+                        const float m0 = (float)(__umulhi(n0, l_magic) >> l_shift);
+                        const float m1 = (float)(__umulhi(n1, l_magic) >> l_shift);
+                        const u32 b0 = (__builtin_bit_cast(u32, m0) & 0x7fffffffu) | ((w[q] << 16) & 0x80000000u);
+                        const u32 b1 = (__builtin_bit_cast(u32, m1) & 0x7fffffffu) | (w[q] & 0x80000000u);
+                        x[2 * q] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, b0), -32768.0f, 32767.0f);
+                        x[2 * q + 1] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, b1), -32768.0f, 32767.0f);
+                    }
+                }
+                // The last real samples of a stream are section 0's x1/x2 for the next launch
+                // (unscaled form here, see above); they pass through exactly one lane each and
+                // are written after the loop.
+                const u32 bf = b * EP_TB;
+                if (l_live && l_n > bf && l_n <= bf + EP_TB) {
+                    const u32 e1 = l_n - 1u - bf;                     // last sample, block relative
+                    if ((e1 >> 3) == l_c) {
+                        float val = x[0];
+#pragma unroll
+                        for (u32 j = 1; j < 8; j++)
+                            val = (e1 & 7u) == j ? x[j] : val;
+                        keep1 = val;
+                        has1 = true;
+                    }
+                    if (e1 >= 1u) {
+                        const u32 e2 = e1 - 1u;
+                        if ((e2 >> 3) == l_c) {
+                            float val = x[0];
+#pragma unroll
+                            for (u32 j = 1; j < 8; j++)
+                                val = (e2 & 7u) == j ? x[j] : val;
+                            keep2 = val;
+                            has2 = true;
+                        }
+                    } else if (l_c == 7u) {
+                        keep2 = sx1[0];                               // the sample before this block
+                        has2 = true;
+                    }
+                }
+#ifdef CMHIP_EQ_STAMPS
+                asm volatile("" : "+v"(x[7]));
+                st_p[1] += __builtin_readcyclecounter() - st_tt;          // converted
+#endif
+                feed_forward(0, x, f);
+                float4 *dst = reinterpret_cast<float4 *>(lds + (b & 1u) * EP_TILE + l_r * EP_ROW + l_t8);
+                dst[0] = make_float4(f[0], f[1], f[2], f[3]);
+                dst[1] = make_float4(f[4], f[5], f[6], f[7]);
+#ifdef CMHIP_EQ_STAMPS
+                asm volatile("" ::: "memory");
+                st_p[2] += __builtin_readcyclecounter() - st_tt;          // F_0 handed to the LDS queue
+#endif
+            }
+            // --- feed-forward of the later sections: Y_k-1 -> F_k
+#pragma unroll
+            for (int k = 1; k < NSEC; k++) {
+                const u32 b = step - HOP * (u32)k;
+                if (!(CMHIP_EQ_ABL & 16) && step >= HOP * (u32)k && b < nblocks) {
+                    const float4 v0 = yin[k][0], v1 = yin[k][1];
+                    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    float f[8];
+                    feed_forward(k, x, f);
+                    float4 *dst = reinterpret_cast<float4 *>(
+                        lds + ((2u * k) * 2u + (b & 1u)) * EP_TILE + l_r * EP_ROW + l_t8);
+                    dst[0] = make_float4(f[0], f[1], f[2], f[3]);
+                    dst[1] = make_float4(f[4], f[5], f[6], f[7]);
+                }
+            }
+        }
+    };
+    auto s_step = [&](const u32 step) {
+        if (!(CMHIP_EQ_ABL & 1)) {
+            // --- the finished block of the last section leaves: 256 B per stream row and
+            // instruction, fire and forget (this wave never waits for global memory)
+            {
+                const u32 b = step - HOP * NSEC;
+                if (step >= HOP * NSEC && b < nblocks) {
+                    const float *Y = lds + ((2u * NSEC - 1u) * 2u + (b & 1u)) * EP_TILE;
+#pragma unroll
+                    for (u32 i = 0; i < G / RPI; i++) {
+                        const u32 r = RPI * i + lane / SPR;
+                        const u32 t4 = (lane % SPR) * 4u;
+                        const u32 f0 = b * EP_TB + t4;
+                        const u32 n = nfr_lds[r];
+                        const float4 v = *reinterpret_cast<const float4 *>(Y + r * EP_ROW + t4);
+                        float *dstf = a.f32 + (u64)(s0 + r) * a.plane + f0;
+                        if (f0 + 4u <= n) {
+                            typedef float f32x4 __attribute__((ext_vector_type(4)));
+                            const f32x4 vv = {v.x, v.y, v.z, v.w};
+                            __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(dstf));
+                        } else if (f0 < n) {
+                            const float e[4] = {v.x, v.y, v.z, v.w};
+                            for (u32 j = 0; j < n - f0; j++)
+                                dstf[j] = e[j];
+                        }
+                    }
+                }
+            }
+        }
+    };
+#ifdef CMHIP_EQ_STAMPS
+#define EQ_STEP(call)                                                   \
+    do {                                                                \
+        const u64 st_t0 = __builtin_readcyclecounter();                 \
+        call;                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+        st_busy += __builtin_readcyclecounter() - st_t0;                \
+        __syncthreads();                                                \
+    } while (0)
+#else
+#define EQ_STEP(call) do { call; __syncthreads(); } while (0)
+#endif
+    // One loop per role (the role never changes, and a loop of its own lets the compiler
+    // count a T wave's outstanding loads); every wave passes the same number of barriers.
+    const u32 nst2 = (nsteps + 1u) & ~1u;                 // an odd tail step finds nothing to do
+    if (is_rec) {
+        float4 ra[EP_TB / 4], rb[EP_TB / 4];
+#pragma unroll
+        for (u32 t = 0; t < EP_TB / 4; t++)
+            ra[t] = rb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (u32 step = 0; step < nst2; step += 2) {
+            EQ_STEP(rec_step(ra, rb, step));
+            EQ_STEP(rec_step(rb, ra, step + 1));
+        }
+    } else if (is_store) {
+        for (u32 step = 0; step < nst2; step++)
+            EQ_STEP(s_step(step));
+    } else {
+        for (u32 step = 0; step < nst2; step += 2) {
+            EQ_STEP(t_step(wa, step));
+            EQ_STEP(t_step(wb, step + 1));
+        }
+        if (has1)
+            a.state[l_s].s[0][0] = keep1 * (1.0f / 32768.0f);
+        if (has2)
+            a.state[l_s].s[0][1] = keep2 * (1.0f / 32768.0f);
     }
+#undef EQ_STEP
 #ifdef CMHIP_EQ_STAMPS
     if (blockIdx.x == 7 && lane == 0 && a.dbg) {     // per-role busy cycles (tools/eq_stamps.py)
         a.dbg[2 * wave] = st_busy;
         a.dbg[2 * wave + 1] = __builtin_readcyclecounter() - st_begin;
-        a.dbg[41 + wave] = st_read;
+        a.dbg[41 + wave] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_ID
         a.dbg[40] = nsteps;
+        if (wave >= NRW && wave < NRW + 2) {          // two T waves: phases inside a step
+            for (int i = 0; i < 3; i++)
+                a.dbg[50 + 3 * (wave - NRW) + i] = st_p[i];
+        }
     }
 #endif
 
+    // state for the next launch.  y1/y2 of section k are also the x1/x2 of section k+1
+    // (its input is this section's output); section 0's x1/x2 were written by the T lanes.
     if (has_sec && live) {
         float *st = a.state[sl].s[sec];
-        if (is_fir) {
-            const float k = sec == 0 ? (1.0f / 32768.0f) : 1.0f;
-            st[0] = h1 * k; st[1] = h2 * k;
-        } else {
-            st[2] = h1; st[3] = h2;
+        st[2] = h1;
+        st[3] = h2;
+        if (sec + 1u < (u32)NSEC) {
+            float *sn = a.state[sl].s[sec + 1u];
+            if (my_nfr >= 2u) {
+                sn[0] = h1;
+                sn[1] = h2;
+            } else if (my_nfr == 1u) {
+                sn[1] = sn[0];
+                sn[0] = h1;
+            }
         }
     }
-    (void)is_store;
 }
 
-template <int NSEC, int G, int TB>
+template <int NSEC, int G>
+static constexpr size_t eq_pipe_lds_bytes()
+{
+    return ((size_t)(2 * NSEC) * 2 * G * (64 + 4)) * sizeof(float) + G * sizeof(u32);
+}
+
+template <int NSEC, int G>
 static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
 {
-    const size_t lds_bytes = ((size_t)(2 * NSEC + 1) * 2 * G * (TB + 4)) * sizeof(float) + G * sizeof(u32);
-    if (lds_bytes > 160 * 1024)
-        return hipErrorInvalidValue;
+    constexpr size_t lds_bytes = eq_pipe_lds_bytes<NSEC, G>();
+    static_assert(lds_bytes <= 160 * 1024, "tiles of a workgroup must fit the LDS");
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G, TB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess)
             return e;
         configured = true;
     }
-    constexpr int SPW = 64 / G, NSW = (NSEC + SPW - 1) / SPW;
-    hipLaunchKernelGGL((k_eq_pipe<NSEC, G, TB>), dim3((a.streams + G - 1) / G),
-                       dim3((2 * NSW + 1 + G / (512 / TB)) * 64), lds_bytes, st, a);
+    constexpr int SPW = 64 / G, NRW = (NSEC + SPW - 1) / SPW;
+    hipLaunchKernelGGL((k_eq_pipe<NSEC, G>), dim3((a.streams + G - 1) / G),
+                       dim3((NRW + G / 8 + 1) * 64), lds_bytes, st, a);
     return hipGetLastError();
 }
 
 template <int NSEC>
 static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st)
 {
-    const char *e = getenv("CMHIP_EQ_G");                 // tuning knobs
-    const char *t = getenv("CMHIP_EQ_TB");
-    int g = e ? atoi(e) : 32;                             // 32 x 64: best on MI355X
-    const int tb = t ? atoi(t) : 64;
-    // the tiles of a workgroup must fit the 160 KiB of LDS
-    auto fits = [&](int gg) { return ((size_t)(2 * NSEC + 1) * 2 * gg * (tb + 4)) * sizeof(float) + gg * sizeof(u32) <= 160 * 1024; };
-    if (g == 32 && !fits(32))
-        g = 16;
-    if (g == 16 && !fits(16))
-        g = 8;
-    if (tb == 128) {
-        if (g == 32) return launch_eq_pipe<NSEC, 32, 128>(a, st);
-        if (g == 16) return launch_eq_pipe<NSEC, 16, 128>(a, st);
-        return launch_eq_pipe<NSEC, 8, 128>(a, st);
-    }
-    if (g == 32) return launch_eq_pipe<NSEC, 32, 64>(a, st);
-    if (g == 16) return launch_eq_pipe<NSEC, 16, 64>(a, st);
-    return launch_eq_pipe<NSEC, 8, 64>(a, st);
+    const char *e = getenv("CMHIP_EQ_G");                 // tuning knob: streams per workgroup
+    const int g = e ? atoi(e) : 32;                       // 32: all 256 CUs at 8192 streams
+    if (g == 16) return launch_eq_pipe<NSEC, 16>(a, st);
+    if (g == 8) return launch_eq_pipe<NSEC, 8>(a, st);
+    return launch_eq_pipe<NSEC, 32>(a, st);
 }
 
 hipError_t launch_eq(const EqArgs &a, hipStream_t st)

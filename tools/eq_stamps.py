@@ -24,4 +24,10 @@ nsteps = out[40]
 print("G =", os.environ.get("CMHIP_EQ_G", "default"), "steps", nsteps)
 for w in range(16):
     if out[2 * w + 1]:
-        print(f"wave {w:2d}: busy {out[2*w]/nsteps:8.1f} clk/step   total {out[2*w+1]/nsteps:8.1f} clk/step   until LDS rows loaded {out[41+w]/nsteps:8.1f}")
+        hw = out[41 + w]
+        print(f"wave {w:2d}: busy {out[2*w]/nsteps:8.1f} clk/step   total {out[2*w+1]/nsteps:8.1f} clk/step   "
+              f"SIMD {(hw >> 4) & 3}  CU {(hw >> 8) & 15}  wave slot {hw & 15}")
+for i in range(2):
+    p = [out[50 + 3 * i + j] / nsteps for j in range(3)]
+    if any(p):
+        print(f"T wave {i}: PCM arrived at {p[0]:7.1f}, converted at {p[1]:7.1f}, F_0 queued at {p[2]:7.1f} clk into the step")
