@@ -790,6 +790,9 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
 // fmaf order the oracle fixes) -> float and/or int16 (+VU of the int16 result).
 // The recurrence runs along time, so a lane owns a stream; 64x64 tiles are moved
 // through LDS so that global loads and stores stay whole 128/256-byte rows.
+// k_eq is the plain form (one wave does everything for 64 streams): it serves the filter
+// bypass (0 sections); batches with 1..4 sections run on k_eq_pipe further down, which is
+// ~30x faster on config 3.
 
 constexpr u32 EQ_TT = 64;           // frames per tile
 constexpr u32 EQ_IN_ROW = 33;       // dwords per int16 row (32 + 1 pad: conflict free)
@@ -970,8 +973,8 @@ __global__ __launch_bounds__(64) void k_eq(EqArgs a)
 #define CMHIP_EQ_ABL 0            // `make abl`: timing-only builds with one part of the pipeline cut out
 #endif
 
-template <int NSEC, int G>
-__global__ __launch_bounds__((((NSEC + 64 / G - 1) / (64 / G)) + G / 8 + 1) * 64)
+template <int NSEC, int G, int NSW>
+__global__ __launch_bounds__((((NSEC + 64 / G - 1) / (64 / G)) + G / 8 + NSW) * 64)
 void k_eq_pipe(EqArgs a)
 {
     constexpr u32 EP_TB = 64;                     // frames per block
@@ -991,7 +994,8 @@ void k_eq_pipe(EqArgs a)
     const u32 s0 = blockIdx.x * G;
 
     const bool is_rec = wave < NRW;
-    const bool is_store = wave == NRW + NTW;              // the S wave
+    const bool is_store = wave >= NRW + NTW;              // the S waves
+    const u32 sw = wave - NRW - NTW;                      // S wave index
     const u32 tw = wave - NRW;                            // T wave index
 
     // R lanes: section and stream row
@@ -1286,30 +1290,86 @@ void k_eq_pipe(EqArgs a)
             }
         }
     };
+    // S wave: per row slot i (rows RPI*i + lane/16) the VU window of the int16 result
+    static_assert((G / RPI) % NSW == 0, "row slots must divide among the S waves");
+    constexpr u32 NSL = G / RPI / NSW;                    // row slots of one S wave
+    u64 vpw[NSL], vky[NSL], vbase[NSL];
+#pragma unroll
+    for (u32 i = 0; i < NSL; i++) {
+        vpw[i] = vky[i] = vbase[i] = 0;
+        const u32 r = RPI * (i * NSW + sw) + lane / SPR;
+        if (is_store && a.vu && s0 + r < a.streams)
+            vbase[i] = a.vu[s0 + r].samples[a.parity];
+    }
     auto s_step = [&](const u32 step) {
         if (!(CMHIP_EQ_ABL & 1)) {
-            // --- the finished block of the last section leaves: 256 B per stream row and
-            // instruction, fire and forget (this wave never waits for global memory)
-            {
-                const u32 b = step - HOP * NSEC;
-                if (step >= HOP * NSEC && b < nblocks) {
-                    const float *Y = lds + ((2u * NSEC - 1u) * 2u + (b & 1u)) * EP_TILE;
+            // --- the finished block of the last section leaves: 256 B (float) / 128 B (int16)
+            // per stream row and instruction, fire and forget (this wave never waits for
+            // global memory); the int16 form is what the VU meter sees
+            const u32 b = step - HOP * NSEC;
+            if (step >= HOP * NSEC && b < nblocks) {
+                const float *Y = lds + ((2u * NSEC - 1u) * 2u + (b & 1u)) * EP_TILE;
 #pragma unroll
-                    for (u32 i = 0; i < G / RPI; i++) {
-                        const u32 r = RPI * i + lane / SPR;
-                        const u32 t4 = (lane % SPR) * 4u;
-                        const u32 f0 = b * EP_TB + t4;
-                        const u32 n = nfr_lds[r];
-                        const float4 v = *reinterpret_cast<const float4 *>(Y + r * EP_ROW + t4);
+                for (u32 i = 0; i < NSL; i++) {
+                    const u32 r = RPI * (i * NSW + sw) + lane / SPR;
+                    const u32 t4 = (lane % SPR) * 4u;
+                    const u32 f0 = b * EP_TB + t4;
+                    const u32 n = nfr_lds[r];
+                    const float4 v = *reinterpret_cast<const float4 *>(Y + r * EP_ROW + t4);
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+                    if (a.f32) {
                         float *dstf = a.f32 + (u64)(s0 + r) * a.plane + f0;
                         if (f0 + 4u <= n) {
                             typedef float f32x4 __attribute__((ext_vector_type(4)));
                             const f32x4 vv = {v.x, v.y, v.z, v.w};
                             __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(dstf));
                         } else if (f0 < n) {
-                            const float e[4] = {v.x, v.y, v.z, v.w};
                             for (u32 j = 0; j < n - f0; j++)
                                 dstf[j] = e[j];
+                        }
+                    }
+                    if (a.out || a.vu) {
+                        int q[4];
+#pragma unroll
+                        for (u32 j = 0; j < 4; j++)
+                            q[j] = f32_to_i16(e[j]);
+                        const bool whole = __all(f0 + 4u <= n);     // no stream ends inside these
+                        if (a.out) {
+                            int16_t *d16 = a.out + (u64)(s0 + r) * a.stride + f0;
+                            if (f0 + 4u <= n) {
+                                typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+                                const u32x2 pk = {((u32)q[0] & 0xffffu) | ((u32)q[1] << 16),
+                                                  ((u32)q[2] & 0xffffu) | ((u32)q[3] << 16)};
+                                __builtin_nontemporal_store(pk, reinterpret_cast<u32x2 *>(d16));
+                            } else if (f0 < n) {
+                                for (u32 j = 0; j < n - f0; j++)
+                                    d16[j] = (int16_t)q[j];
+                            }
+                        }
+                        if (a.vu) {
+                            u32 am[4];
+#pragma unroll
+                            for (u32 j = 0; j < 4; j++) {
+                                am[j] = (u32)(q[j] < 0 ? -q[j] : q[j]);
+                                if (!whole)
+                                    am[j] = f0 + j < n ? am[j] : 0u;
+                            }
+#pragma unroll
+                            for (u32 j = 0; j < 4; j++)
+                                vpw[i] += (u64)am[j] * am[j];
+                            u32 m = am[0], jm = 0;                     // first of the largest
+#pragma unroll
+                            for (u32 j = 1; j < 4; j++) {
+                                const bool gt = am[j] > m;
+                                m = gt ? am[j] : m;
+                                jm = gt ? j : jm;
+                            }
+                            int qm = q[0];
+#pragma unroll
+                            for (u32 j = 1; j < 4; j++)
+                                qm = jm == j ? q[j] : qm;
+                            const u64 kk = make_key(m, vbase[i] + f0 + jm, qm < 0 ? 1u : 0u);
+                            vky[i] = kk > vky[i] ? kk : vky[i];
                         }
                     }
                 }
@@ -1343,6 +1403,27 @@ void k_eq_pipe(EqArgs a)
     } else if (is_store) {
         for (u32 step = 0; step < nst2; step++)
             EQ_STEP(s_step(step));
+        if (a.vu) {
+            // the 16 lanes of a row hold parts of its window; lane 0 of them is the row's only writer
+#pragma unroll
+            for (u32 i = 0; i < NSL; i++) {
+                u64 pw = vpw[i], ky = vky[i];
+#pragma unroll
+                for (int o = SPR / 2; o > 0; o >>= 1) {
+                    pw += (u64)__shfl_xor((long long)pw, o, 64);
+                    const u64 ok = (u64)__shfl_xor((long long)ky, o, 64);
+                    ky = ok > ky ? ok : ky;
+                }
+                const u32 r = RPI * (i * NSW + sw) + lane / SPR;
+                if (lane % SPR == 0 && s0 + r < a.streams) {
+                    VuState *vs = a.vu + s0 + r;
+                    vs->samples[a.parity ^ 1u] = vbase[i] + nfr_lds[r];
+                    vs->power[0] += pw;
+                    if (ky > vs->key[0])
+                        vs->key[0] = ky;
+                }
+            }
+        }
     } else {
         for (u32 step = 0; step < nst2; step += 2) {
             EQ_STEP(t_step(wa, step));
@@ -1392,22 +1473,22 @@ static constexpr size_t eq_pipe_lds_bytes()
     return ((size_t)(2 * NSEC) * 2 * G * (64 + 4)) * sizeof(float) + G * sizeof(u32);
 }
 
-template <int NSEC, int G>
+template <int NSEC, int G, int NSW>
 static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
 {
     constexpr size_t lds_bytes = eq_pipe_lds_bytes<NSEC, G>();
     static_assert(lds_bytes <= 160 * 1024, "tiles of a workgroup must fit the LDS");
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G, NSW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess)
             return e;
         configured = true;
     }
     constexpr int SPW = 64 / G, NRW = (NSEC + SPW - 1) / SPW;
-    hipLaunchKernelGGL((k_eq_pipe<NSEC, G>), dim3((a.streams + G - 1) / G),
-                       dim3((NRW + G / 8 + 1) * 64), lds_bytes, st, a);
+    hipLaunchKernelGGL((k_eq_pipe<NSEC, G, NSW>), dim3((a.streams + G - 1) / G),
+                       dim3((NRW + G / 8 + NSW) * 64), lds_bytes, st, a);
     return hipGetLastError();
 }
 
@@ -1416,36 +1497,29 @@ static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st)
 {
     const char *e = getenv("CMHIP_EQ_G");                 // tuning knob: streams per workgroup
     const int g = e ? atoi(e) : 32;                       // 32: all 256 CUs at 8192 streams
-    if (g == 16) return launch_eq_pipe<NSEC, 16>(a, st);
-    if (g == 8) return launch_eq_pipe<NSEC, 8>(a, st);
-    return launch_eq_pipe<NSEC, 32>(a, st);
+    // the int16 conversion and the VU window are per-sample work of the S waves: more of them
+    const bool heavy = a.out || a.vu;
+    if (g == 16)
+        return heavy ? launch_eq_pipe<NSEC, 16, 4>(a, st) : launch_eq_pipe<NSEC, 16, 1>(a, st);
+    if (g == 8)
+        return heavy ? launch_eq_pipe<NSEC, 8, 2>(a, st) : launch_eq_pipe<NSEC, 8, 1>(a, st);
+    return heavy ? launch_eq_pipe<NSEC, 32, 4>(a, st) : launch_eq_pipe<NSEC, 32, 1>(a, st);
 }
 
 hipError_t launch_eq(const EqArgs &a, hipStream_t st)
 {
-    const dim3 grid((a.streams + 63) / 64), block(64);
-    if (a.streams == 0 || a.frames == 0)
+    if (a.streams == 0 || a.frames == 0 || !(a.f32 || a.out || a.vu))
         return hipSuccess;
-    // float output only, 1..4 sections: the pipelined kernel; everything else (int16
-    // result, VU of it, bypass) takes the one-wave-per-tile kernel below
-    if (a.f32 && !a.out && !a.vu) {
-        switch (a.nsec) {
-        case 1: return launch_eq_pipe_g<1>(a, st);
-        case 2: return launch_eq_pipe_g<2>(a, st);
-        case 3: return launch_eq_pipe_g<3>(a, st);
-        case 4: return launch_eq_pipe_g<4>(a, st);
-        default: break;
-        }
-    }
     switch (a.nsec) {
-    case 0: hipLaunchKernelGGL(k_eq<0>, grid, block, 0, st, a); break;
-    case 1: hipLaunchKernelGGL(k_eq<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(k_eq<2>, grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(k_eq<3>, grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(k_eq<4>, grid, block, 0, st, a); break;
+    case 0:                                               // filter bypass: gain and conversion only
+        hipLaunchKernelGGL(k_eq<0>, dim3((a.streams + 63) / 64), dim3(64), 0, st, a);
+        return hipGetLastError();
+    case 1: return launch_eq_pipe_g<1>(a, st);            // the pipelined kernel, whatever is asked
+    case 2: return launch_eq_pipe_g<2>(a, st);            // for (float planes, int16, VU of it)
+    case 3: return launch_eq_pipe_g<3>(a, st);
+    case 4: return launch_eq_pipe_g<4>(a, st);
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------

@@ -138,3 +138,55 @@ def test_eq_pipelined_kernel_ragged_and_state_carry(gpu, oracle, nsec):
             wf, _ = want[k]
             assert np.array_equal(got[s][k].view(np.uint32), wf.view(np.uint32)), (nsec, s, k)
     b.close()
+
+
+@pytest.mark.parametrize("gain_mode,inplace", [("off", False), ("unity", False), ("mixed", True)])
+def test_eq_pipelined_int16_and_vu_only(gpu, oracle, gain_mode, inplace):
+    """the chain a VU meter or encoder sits behind: EQ result as int16 (+VU window), no float
+    planes.  gain off / gain == scale take the conversion short cut of the pipelined kernel;
+    the in-place case overwrites the input PCM with the result"""
+    cm = gpu
+    rng = np.random.default_rng(4242 + len(gain_mode))
+    S, T = 75, 400
+    coef = cm.eq3(48000.0)
+    flags = cm.EQ | cm.OUT_PCM | cm.VU | (cm.INPLACE if inplace else 0)
+    b = cm.Batch(S, 1, T, flags=flags)
+    assert b.set_eq(-1, coef) == 0
+    gains = []
+    for s in range(S):
+        if gain_mode == "off":
+            ga = None
+        elif gain_mode == "unity":
+            ga = (1, 777, [777])
+        else:
+            ga = None if s % 5 == 0 else (1, 1000, [int(rng.integers(100, 3000))])
+        if ga:
+            assert b.set_gain(s, *ga) == 0
+        gains.append(ga)
+    all_lens = []
+    for k in range(2):
+        lens = [int(v) for v in rng.integers(0, T + 1, S)]
+        lens[0], lens[1], lens[2], lens[3] = T, 1 - k, 2, 64
+        all_lens.append(lens)
+    blocks = [[rng.integers(-32768, 32768, all_lens[k][s]).astype(np.int16) for k in range(2)]
+              for s in range(S)]
+    got = [[None] * 2 for _ in range(S)]
+    for k in range(2):
+        for s in range(S):
+            if all_lens[k][s]:
+                b.upload(s, blocks[s][k])
+        b.run(T, frames_per_stream=all_lens[k])
+        for s in range(S):
+            got[s][k] = b.download(s, all_lens[k][s])
+    for s in range(S):
+        want = _oracle_eq(oracle, coef, 3, gains[s], blocks[s])
+        v = oracle.vu_new(1)
+        for k in range(2):
+            assert np.array_equal(got[s][k], want[k][1]), (gain_mode, s, k)
+            oracle.vu_accumulate(v, want[k][1])
+        rc_o, r_o = oracle.vu_result(v)
+        rc_g, r_g = b.vu_result(s)
+        assert rc_g == rc_o, (gain_mode, s)
+        if rc_o == 0:
+            assert r_g.as_dict() == of.vu_result_dict(r_o), (gain_mode, s)
+    b.close()
