@@ -426,7 +426,8 @@ __global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// Wide path: 4, 8 or 16 channels with the identity channel map.  Same tile scheme and the
+// Wide path: 4 or 8 channels with the identity channel map (the template also covers 16,
+// which k_run_rows now serves faster).  Same tile scheme and the
 // same packed arithmetic as k_run_fast; a 16-byte vector holds 8/C frames, so every vector
 // position has a fixed channel (for 16 channels: fixed per lane parity) and the per-channel
 // accumulators live in registers.  NS = min(C, 8) accumulator slots per lane: the half h of
@@ -616,6 +617,176 @@ __global__ __launch_bounds__(64) void k_run_wide(RunArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Row path: any channel count, identity channel map (3, 5, 6 = 5.1, 7, 9...16 channels; 1, 2,
+// 4 and 8 have the kernels above).  The channel of a sample is (8*v + j) mod C for
+// vector v and position j, which changes from vector to vector -- unless the vectors a lane
+// visits are a multiple of P = C / gcd(C, 8) apart.  So a wave walks ROWS of W = 64 - 64 % P
+// vectors (63, 60, 55 or 52 of the 64 lanes work): rows are contiguous, loads and stores stay
+// coalesced, and position j of a lane has the same channel in every row.  Gains and
+// per-position accumulators are then per-lane constants / registers, exactly the packed
+// arithmetic of the kernels above; only the final merge differs (positions of different
+// lanes hold different channels: LDS atomics by channel, once per wave).
+
+template <bool WRITE_PCM, bool WRITE_F32, bool DO_VU>
+__global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_tile)
+{
+    constexpr u32 UR = 4;                        // rows in flight
+    __shared__ u64 lsum[MAX_CH];
+    __shared__ u64 lkey[MAX_CH];
+    const u32 lane = threadIdx.x;
+    const u32 s = blockIdx.x / a.chunks;
+    const u32 k = blockIdx.x - s * a.chunks;
+    const u32 C = a.channels;
+
+    const u32 nfr = a.nframes ? a.nframes[s] : a.frames;
+    const u32 nsamp = nfr * C;
+    const u32 nfull = nsamp >> 3;                // whole 16-byte vectors
+    const u32 ntail = nsamp & 7u;                // samples in the partial last vector
+    const u32 nvec = nfull + (ntail ? 1u : 0u);
+    const u32 row0 = k * rows_per_tile;
+
+    VuState *vs = DO_VU ? a.vu + s : nullptr;
+    u64 base = 0;
+    if constexpr (DO_VU) {
+        base = vs->samples[a.parity];
+        if (k == 0 && lane == 0)
+            vs->samples[a.parity ^ 1u] = base + nsamp;
+    }
+    if ((u64)row0 * W >= nvec)
+        return;
+    if constexpr (DO_VU) {
+        if (lane < MAX_CH) {
+            lsum[lane] = 0;
+            lkey[lane] = 0;
+        }
+    }
+
+    const StreamParam *p = a.param + s;
+    const u32 magic = p->magic, shift = p->shift;
+    const bool active = lane < W;
+    const u32 lane_fr = 8u * lane / C;           // whole frames before this lane's vector in a row
+    const u32 phase = 8u * lane - lane_fr * C;   // channel of its position 0
+    const u32 FW = 8u * W / C;                   // frames per row (8W is a multiple of C)
+    u32 ch[8], df[8], g2[8];
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+        const u32 t = phase + j;
+        df[j] = t / C;
+        ch[j] = t - df[j] * C;
+        g2[j] = p->gain2[ch[j]];
+    }
+
+    const int16_t *ins = a.in + (u64)s * a.stride;
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(ins);
+    int16_t *outs = WRITE_PCM ? a.out + (u64)s * a.stride : nullptr;
+    u32x4 *dst = reinterpret_cast<u32x4 *>(outs);
+    float *f32s = WRITE_F32 ? a.f32 + (u64)s * a.plane * C : nullptr;
+
+    PowAcc pw[8];
+    u32 best[8];                                 // |peak| << 16 | (0x7fff - row in tile) << 1 | negative
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+        pw[j] = PowAcc{0, 0, 0};
+        best[j] = 0;
+    }
+
+    for (u32 r0 = 0; r0 < rows_per_tile; r0 += UR) {
+        if ((u64)(row0 + r0) * W >= nvec)
+            break;
+        u32 x[UR][4];
+        bool full[UR], tail[UR];
+#pragma unroll
+        for (u32 u = 0; u < UR; u++) {
+            const u32 v = (row0 + r0 + u) * W + lane;
+            full[u] = active && v < nfull;
+            tail[u] = active && ntail && v == nfull;
+            u32x4 w = {0, 0, 0, 0};
+            if (full[u])
+                w = __builtin_nontemporal_load(src + v);
+            x[u][0] = w.x; x[u][1] = w.y; x[u][2] = w.z; x[u][3] = w.w;
+            if (tail[u]) {
+                for (u32 j = 0; j < ntail; j++) {
+                    const u32 val = (u32)(uint16_t)ins[(u64)v * 8 + j];
+#pragma unroll
+                    for (u32 i = 0; i < 4; i++)
+                        if (i == (j >> 1))
+                            x[u][i] |= val << (16u * (j & 1u));
+                }
+            }
+        }
+#pragma unroll
+        for (u32 u = 0; u < UR; u++) {
+            const u32 row = row0 + r0 + u;
+            const u32 v = row * W + lane;
+            u32 o[4];
+            const u32 tag = (0x7fffu - (r0 + u)) << 1;
+#pragma unroll
+            for (u32 i = 0; i < 4; i++) {
+                const u32 qw = gain2(x[u][i], g2[2 * i], g2[2 * i + 1], magic, shift, o[i]);
+                if constexpr (DO_VU) {
+                    best[2 * i] = max(best[2 * i], (qw << 16) | tag | ((x[u][i] >> 15) & 1u));
+                    best[2 * i + 1] = max(best[2 * i + 1], (qw & 0xffff0000u) | tag | (x[u][i] >> 31));
+                    pw[2 * i].add_lo(qw);
+                    pw[2 * i + 1].add_hi(qw);
+                }
+            }
+            if (full[u]) {
+                if constexpr (WRITE_PCM) {
+                    const u32x4 ov = {o[0], o[1], o[2], o[3]};
+                    __builtin_nontemporal_store(ov, dst + v);
+                }
+            } else if (tail[u]) {
+                if constexpr (WRITE_PCM) {
+                    for (u32 j = 0; j < ntail; j++) {
+                        u32 ow = 0;
+#pragma unroll
+                        for (u32 i = 0; i < 4; i++)
+                            if (i == (j >> 1))
+                                ow = o[i];
+                        outs[(u64)v * 8 + j] = (int16_t)((ow >> (16u * (j & 1u))) & 0xffffu);
+                    }
+                }
+            }
+            if constexpr (WRITE_F32) {
+                const u32 cnt = full[u] ? 8u : (tail[u] ? ntail : 0u);
+                const u32 fr = row * FW + lane_fr;
+#pragma unroll
+                for (u32 j = 0; j < 8; j++) {
+                    if (j < cnt) {
+                        const int q = (int)(short)((o[j >> 1] >> (16u * (j & 1u))) & 0xffffu);
+                        f32s[(u64)ch[j] * a.plane + fr + df[j]] = q * (1.0f / 32768.0f);
+                    }
+                }
+            }
+        }
+    }
+
+    if constexpr (DO_VU) {
+        __syncthreads();                         // accumulators cleared (one wave: cheap)
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) {
+            pw[j].flush();
+            if (pw[j].total)
+                atomicAdd(reinterpret_cast<unsigned long long *>(&lsum[ch[j]]), (unsigned long long)pw[j].total);
+            const u32 mag = best[j] >> 16;
+            if (mag) {
+                const u32 rr = 0x7fffu - ((best[j] >> 1) & 0x7fffu);
+                const u64 v = (u64)(row0 + rr) * W + lane;
+                const u64 key = make_key(mag, base + 8ull * v + j, best[j] & 1u);
+                atomicMax(reinterpret_cast<unsigned long long *>(&lkey[ch[j]]), (unsigned long long)key);
+            }
+        }
+        __syncthreads();
+        if (lane < C) {
+            if (lsum[lane])
+                atomicAdd(&vs->power[lane], lsum[lane]);
+            if (lkey[lane])
+                atomicMax(&vs->key[lane], lkey[lane]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // General path: any channel count up to 16, any channel map.  One thread per frame.
 
 __global__ __launch_bounds__(256) void k_run_generic(RunArgs a, u32 blocks_per_stream)
@@ -739,11 +910,11 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
             CMHIP_FAST_C(2);
 #undef CMHIP_FAST_C
 #undef CMHIP_FAST
-    } else if ((a.channels == 4 || a.channels == 8 || a.channels == 16) && a.identity_maps) {
+    } else if ((a.channels == 4 || a.channels == 8) && a.identity_maps) {
         RunArgs b = a;
-        // tile size: the epilogue grows with the channel count, so 16 channels and read-only
-        // runs take 16 KiB tiles, the rest 8 KiB (tools/bench_generic.py)
-        const u32 wu = (a.channels == 16 || (!pcm && !f32)) ? 16u : 8u;
+        // tile size: read-only runs take 16 KiB tiles, the rest 8 KiB (tools/bench_generic.py);
+        // 16 channels run faster on k_run_rows below (5.6 against 4.7 TB/s)
+        const u32 wu = (!pcm && !f32) ? 16u : 8u;
         const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
         b.chunks = (u32)((nvec + 64ull * wu - 1) / (64ull * wu));
         if (b.chunks == 0)
@@ -770,13 +941,41 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
     } while (0)
         if (a.channels == 4)
             CMHIP_WIDE_C(4);
-        else if (a.channels == 8)
-            CMHIP_WIDE_C(8);
         else
-            CMHIP_WIDE_C(16);
+            CMHIP_WIDE_C(8);
 #undef CMHIP_WIDE_C
 #undef CMHIP_WIDE
+    } else if (a.identity_maps) {
+        // any other channel count: rows of W vectors so that every lane position keeps its channel
+        RunArgs b = a;
+        u32 g = a.channels, e = 8;
+        while (e) {                              // gcd(C, 8)
+            const u32 t = g % e;
+            g = e;
+            e = t;
+        }
+        const u32 P = a.channels / g;
+        const u32 W = 64u - 64u % P;
+        const u32 rpt = (!pcm && !f32) ? 16u : 8u;            // rows per tile (~1 KiB each)
+        const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
+        const u64 rows = (nvec + W - 1) / W;
+        b.chunks = (u32)((rows + rpt - 1) / rpt);
+        if (b.chunks == 0)
+            b.chunks = 1;
+        if ((u64)b.chunks * a.streams >= (1ull << 31))
+            return hipErrorInvalidValue;
+        const u32 grid = a.streams * b.chunks;
+#define CMHIP_ROWS(P_, F_, V_) hipLaunchKernelGGL((k_run_rows<P_, F_, V_>), dim3(grid), dim3(64), 0, st, b, W, rpt)
+        if (pcm && !f32 && vu) CMHIP_ROWS(true, false, true);
+        else if (!pcm && !f32 && vu) CMHIP_ROWS(false, false, true);
+        else if (pcm && !f32 && !vu) CMHIP_ROWS(true, false, false);
+        else if (pcm && f32 && vu) CMHIP_ROWS(true, true, true);
+        else if (!pcm && f32 && vu) CMHIP_ROWS(false, true, true);
+        else if (pcm && f32 && !vu) CMHIP_ROWS(true, true, false);
+        else if (!pcm && f32 && !vu) CMHIP_ROWS(false, true, false);
+#undef CMHIP_ROWS
     } else {
+        // a channel map that moves samples across 16-byte vectors: one thread per frame
         u32 bps = (a.frames + 255u) / 256u;
         if (bps > 64u)
             bps = 64u;

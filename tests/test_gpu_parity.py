@@ -434,13 +434,14 @@ def test_full_size_config2_properties(gpu, oracle):
     v.close()
 
 
-@pytest.mark.parametrize("C", [4, 8, 16])
+@pytest.mark.parametrize("C", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 def test_wide_channel_kernels(gpu, oracle, C):
-    """4/8/16 channels with identity maps take k_run_wide: ragged lengths, per-stream gains,
-    in place and not, VU only, float planes, windows over two launches"""
+    """more than two channels with identity maps take the vector kernels (k_run_wide for 4/8/16,
+    k_run_rows for every other count): ragged lengths, per-stream gains, in place and not,
+    VU only, float planes, windows over two launches"""
     cm = gpu
     rng = np.random.default_rng(500 + C)
-    lens = [0, 1, 2, 3, 63, 64, 65, 127, 128, 129, 511, 1000, 1023, 1024, 1025, 3000]
+    lens = [0, 1, 2, 3, 63, 64, 65, 127, 128, 129, 511, 1000, 1023, 1024, 1025, 3000, 9973]
     S, T = len(lens), max(lens)
     xs = [_rand_pcm(rng, lens[s] * C, ["full", "edges", "small"][s % 3]) for s in range(S)]
     gas = []

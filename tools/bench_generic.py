@@ -8,7 +8,7 @@ import __graft_entry__ as ge
 
 cm = ge.load_package()
 T = 16384
-for C in (3, 4, 6, 8, 16):
+for C in (3, 6, 4, 8, 16):
     S = (1 << 28) // (T * C)          # ~0.5 GB of PCM
     for flags, name, bps in ((cm.OUT_PCM | cm.VU, "pcm+vu", 4), (cm.VU, "vu only", 2)):
         b = cm.Batch(S, C, T, flags=flags)
