@@ -627,12 +627,18 @@ __global__ __launch_bounds__(64) void k_run_wide(RunArgs a)
 // arithmetic of the kernels above; only the final merge differs (positions of different
 // lanes hold different channels: LDS atomics by channel, once per wave).
 
-template <bool WRITE_PCM, bool WRITE_F32, bool DO_VU>
+//
+// MAP: the streams carry channel maps.  A row holds whole frames, so a mapped sample's source
+// lies in the same row: the raw row goes through LDS and every position gathers its source
+// with a 16-bit read at a per-lane constant offset.
+
+template <bool WRITE_PCM, bool WRITE_F32, bool DO_VU, bool MAP>
 __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_tile)
 {
     constexpr u32 UR = 4;                        // rows in flight
     __shared__ u64 lsum[MAX_CH];
     __shared__ u64 lkey[MAX_CH];
+    __shared__ u32x4 raw[MAP ? UR * 64 : 1];     // the rows as loaded (MAP only)
     const u32 lane = threadIdx.x;
     const u32 s = blockIdx.x / a.chunks;
     const u32 k = blockIdx.x - s * a.chunks;
@@ -668,12 +674,14 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
     const u32 phase = 8u * lane - lane_fr * C;   // channel of its position 0
     const u32 FW = 8u * W / C;                   // frames per row (8W is a multiple of C)
     u32 ch[8], df[8], g2[8];
+    u32 so[8];                                   // MAP: byte offset of position j's source in its row
 #pragma unroll
     for (u32 j = 0; j < 8; j++) {
         const u32 t = phase + j;
         df[j] = t / C;
         ch[j] = t - df[j] * C;
         g2[j] = p->gain2[ch[j]];
+        so[j] = MAP ? 2u * ((lane_fr + df[j]) * C + p->chmap[ch[j]]) : 0u;
     }
 
     const int16_t *ins = a.in + (u64)s * a.stride;
@@ -711,6 +719,25 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
                     for (u32 i = 0; i < 4; i++)
                         if (i == (j >> 1))
                             x[u][i] |= val << (16u * (j & 1u));
+                }
+            }
+        }
+        if constexpr (MAP) {
+            __syncthreads();                     // the previous rows have been gathered
+#pragma unroll
+            for (u32 u = 0; u < UR; u++)
+                raw[u * 64u + lane] = u32x4{x[u][0], x[u][1], x[u][2], x[u][3]};
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (u32 u = 0; u < UR; u++) {
+                    const unsigned char *rowb = reinterpret_cast<const unsigned char *>(raw + u * 64u);
+#pragma unroll
+                    for (u32 i = 0; i < 4; i++) {
+                        const u32 lo = *reinterpret_cast<const uint16_t *>(rowb + so[2 * i]);
+                        const u32 hi = *reinterpret_cast<const uint16_t *>(rowb + so[2 * i + 1]);
+                        x[u][i] = lo | (hi << 16);
+                    }
                 }
             }
         }
@@ -787,83 +814,7 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
 }
 
 // ---------------------------------------------------------------------------
-// General path: any channel count up to 16, any channel map.  One thread per frame.
-
-__global__ __launch_bounds__(256) void k_run_generic(RunArgs a, u32 blocks_per_stream)
-{
-    __shared__ u64 lpow[MAX_CH];
-    __shared__ u64 lkey[MAX_CH];
-    const u32 s = blockIdx.x / blocks_per_stream;
-    const u32 fb = blockIdx.x - s * blocks_per_stream;
-    const u32 C = a.channels;
-    if (threadIdx.x < MAX_CH) {
-        lpow[threadIdx.x] = 0;
-        lkey[threadIdx.x] = 0;
-    }
-    __syncthreads();
-
-    const u32 nfr = a.nframes ? a.nframes[s] : a.frames;
-    const StreamParam *p = a.param + s;
-    const u32 magic = p->magic, shift = p->shift;
-    const int16_t *ins = a.in + (u64)s * a.stride;
-    int16_t *outs = a.out ? a.out + (u64)s * a.stride : nullptr;
-    float *f32s = a.f32 ? a.f32 + (u64)s * a.plane * C : nullptr;
-    const u64 base = a.vu ? a.vu[s].samples[a.parity] : 0;
-    if (a.vu && fb == 0 && threadIdx.x == 0)
-        a.vu[s].samples[a.parity ^ 1u] = base + (u64)nfr * C;
-
-    u64 pw[MAX_CH], ky[MAX_CH];
-#pragma unroll
-    for (u32 c = 0; c < MAX_CH; c++) {
-        pw[c] = 0;
-        ky[c] = 0;
-    }
-
-    for (u32 f = fb * 256u + threadIdx.x; f < nfr; f += blocks_per_stream * 256u) {
-        int x[MAX_CH];
-#pragma unroll
-        for (u32 c = 0; c < MAX_CH; c++)
-            x[c] = c < C ? (int)ins[(u64)f * C + p->chmap[c]] : 0;      // whole frame first: in-place safe
-#pragma unroll
-        for (u32 c = 0; c < MAX_CH; c++) {
-            if (c < C) {
-                int sg;
-                const u32 m = gain_mag(x[c], p->gain2[c], magic, shift, sg);
-                const int q = (int)((m ^ (u32)sg) - (u32)sg);
-                if (outs)
-                    outs[(u64)f * C + c] = (int16_t)q;
-                if (f32s)
-                    f32s[(u64)c * a.plane + f] = q * (1.0f / 32768.0f);
-                pw[c] += (u64)(m * m);
-                const u64 kk = make_key(m, base + (u64)f * C + c, (u32)(sg & 1));
-                ky[c] = kk > ky[c] ? kk : ky[c];
-            }
-        }
-    }
-
-    if (a.vu) {
-#pragma unroll
-        for (u32 c = 0; c < MAX_CH; c++) {
-            if (c < C) {
-                const u64 sum = wave_sum(pw[c]);
-                const u64 key = wave_max(ky[c]);
-                if ((threadIdx.x & 63u) == 0) {
-                    if (sum)
-                        atomicAdd(&lpow[c], sum);
-                    if (key)
-                        atomicMax(&lkey[c], key);
-                }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < C) {
-            if (lpow[threadIdx.x])
-                atomicAdd(&a.vu[s].power[threadIdx.x], lpow[threadIdx.x]);
-            if (lkey[threadIdx.x])
-                atomicMax(&a.vu[s].key[threadIdx.x], lkey[threadIdx.x]);
-        }
-    }
-}
+// Launcher of the block kernels: by channel count and by what the batch asks for.
 
 hipError_t launch_run(const RunArgs &a, hipStream_t st)
 {
@@ -945,8 +896,9 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
             CMHIP_WIDE_C(8);
 #undef CMHIP_WIDE_C
 #undef CMHIP_WIDE
-    } else if (a.identity_maps) {
-        // any other channel count: rows of W vectors so that every lane position keeps its channel
+    } else {
+        // any other channel count, or channel maps on more than two channels: rows of W vectors
+        // so that every lane position keeps its channel
         RunArgs b = a;
         u32 g = a.channels, e = 8;
         while (e) {                              // gcd(C, 8)
@@ -956,7 +908,9 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
         }
         const u32 P = a.channels / g;
         const u32 W = 64u - 64u % P;
-        const u32 rpt = (!pcm && !f32) ? 16u : 8u;            // rows per tile (~1 KiB each)
+        // rows per tile (~1 KiB each); with 4 or 8 channels (here only when they carry channel
+        // maps) every lane adds to the same few LDS words at the end: bigger tiles, fewer merges
+        const u32 rpt = P == 1 ? 32u : (!pcm && !f32) ? 16u : 8u;
         const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
         const u64 rows = (nvec + W - 1) / W;
         b.chunks = (u32)((rows + rpt - 1) / rpt);
@@ -965,7 +919,13 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
         if ((u64)b.chunks * a.streams >= (1ull << 31))
             return hipErrorInvalidValue;
         const u32 grid = a.streams * b.chunks;
-#define CMHIP_ROWS(P_, F_, V_) hipLaunchKernelGGL((k_run_rows<P_, F_, V_>), dim3(grid), dim3(64), 0, st, b, W, rpt)
+#define CMHIP_ROWS(P_, F_, V_)                                                                      \
+    do {                                                                                            \
+        if (a.identity_maps)                                                                        \
+            hipLaunchKernelGGL((k_run_rows<P_, F_, V_, false>), dim3(grid), dim3(64), 0, st, b, W, rpt); \
+        else                                                                                        \
+            hipLaunchKernelGGL((k_run_rows<P_, F_, V_, true>), dim3(grid), dim3(64), 0, st, b, W, rpt);  \
+    } while (0)
         if (pcm && !f32 && vu) CMHIP_ROWS(true, false, true);
         else if (!pcm && !f32 && vu) CMHIP_ROWS(false, false, true);
         else if (pcm && !f32 && !vu) CMHIP_ROWS(true, false, false);
@@ -974,12 +934,6 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
         else if (pcm && f32 && !vu) CMHIP_ROWS(true, true, false);
         else if (!pcm && f32 && !vu) CMHIP_ROWS(false, true, false);
 #undef CMHIP_ROWS
-    } else {
-        // a channel map that moves samples across 16-byte vectors: one thread per frame
-        u32 bps = (a.frames + 255u) / 256u;
-        if (bps > 64u)
-            bps = 64u;
-        hipLaunchKernelGGL(k_run_generic, dim3(a.streams * bps), dim3(256), 0, st, a, bps);
     }
     return hipGetLastError();
 }

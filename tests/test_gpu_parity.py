@@ -489,6 +489,55 @@ def test_wide_channel_kernels(gpu, oracle, C):
         b.close()
 
 
+@pytest.mark.parametrize("C", [3, 4, 6, 8, 13, 16])
+def test_channel_maps_on_many_channels(gpu, oracle, C):
+    """channel maps (permutations and maps that repeat a channel) on more than two channels:
+    k_run_rows gathers through LDS; every output set, in place, ragged lengths"""
+    cm = gpu
+    rng = np.random.default_rng(900 + C)
+    lens = [0, 1, 2, 5, 63, 64, 65, 500, 1021, 1024, 2049, 7777]
+    S, T = len(lens), max(lens)
+    xs = [_rand_pcm(rng, lens[s] * C, ["full", "edges", "small"][s % 3]) for s in range(S)]
+    gas, maps = [], []
+    for s in range(S):
+        gas.append(None if s % 3 == 0 else
+                   (C, int(rng.integers(1, 65536)), [int(v) for v in rng.integers(0, 65536, C)]))
+        if s % 4 == 3:
+            maps.append(None)                                   # a stream without a map among mapped ones
+        elif s % 2 == 0:
+            maps.append([int(v) for v in rng.permutation(C)])
+        else:
+            maps.append([int(v) for v in rng.integers(0, C, C)])
+    wants = [_oracle_block(oracle, xs[s], C, gas[s], maps[s]) for s in range(S)]
+    for flags in (cm.OUT_PCM | cm.VU, cm.OUT_PCM | cm.VU | cm.INPLACE, cm.VU,
+                  cm.OUT_F32 | cm.OUT_PCM | cm.VU, cm.OUT_F32):
+        b = cm.Batch(S, C, T, flags=flags)
+        for s in range(S):
+            if gas[s] is not None:
+                assert b.set_gain(s, *gas[s]) == 0
+            if maps[s] is not None:
+                assert b.set_chmap(s, maps[s]) == 0
+            if lens[s]:
+                b.upload(s, xs[s])
+        b.run(T, frames_per_stream=lens)
+        for s in range(S):
+            if flags & cm.OUT_PCM:
+                got = b.download(s, lens[s]) if lens[s] else np.zeros(0, np.int16)
+                assert np.array_equal(got, wants[s]), (C, s, flags)
+            if flags & cm.OUT_F32 and lens[s]:
+                planar = oracle.to_f32_planar(wants[s], C)
+                for c in range(C):
+                    gotf = b.download_f32(s, c, lens[s])
+                    assert np.array_equal(gotf.view(np.uint32), planar[c].view(np.uint32)), (C, s, c)
+            if flags & cm.VU:
+                rc_o, r_o = _oracle_vu(oracle, [wants[s]], C)
+                rc_g, r_g = b.vu_result(s)
+                assert rc_g == rc_o, (C, s, flags)
+                if rc_o == 0:
+                    assert r_g.as_dict() == of.vu_result_dict(r_o), (C, s, flags)
+        b.close()
+
+
 def test_batch_api_error_paths(gpu):
     """argument checking of the C ABI (include/coolmic_hip.h): errors are numbers, never faults"""
     import ctypes as C

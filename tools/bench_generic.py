@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Kernel time of the many-channel path (k_run_generic) for a few channel counts."""
+"""Kernel time of the many-channel kernels (k_run_wide, k_run_rows) for a few channel counts,
+with identity maps and with a channel map (rotation by one channel)."""
 import os
 import sys
 
@@ -8,11 +9,14 @@ import __graft_entry__ as ge
 
 cm = ge.load_package()
 T = 16384
-for C in (3, 6, 4, 8, 16):
+for C in (3, 5, 6, 7, 12, 15, 4, 8, 16):
     S = (1 << 28) // (T * C)          # ~0.5 GB of PCM
-    for flags, name, bps in ((cm.OUT_PCM | cm.VU, "pcm+vu", 4), (cm.VU, "vu only", 2)):
+    for flags, name, bps, mapped in ((cm.OUT_PCM | cm.VU, "pcm+vu", 4, False), (cm.VU, "vu only", 2, False),
+                                     (cm.OUT_PCM | cm.VU, "pcm+vu, mapped", 4, True)):
         b = cm.Batch(S, C, T, flags=flags)
         b.set_gain(-1, 1, 1000, [900])
+        if mapped:
+            b.set_chmap(-1, [(c + 1) % C for c in range(C)])
         b.generate(cm.GEN_NOISE, 1, T)
         for _ in range(2):
             b.run(T)
@@ -23,5 +27,5 @@ for C in (3, 6, 4, 8, 16):
             b.run(T)
         ms, n = b.timing_read()
         gbs = S * C * T * bps / (ms / n * 1e-3) / 1e9
-        print(f"C={C:2d} S={S:5d} {name:8s} {ms/n:8.3f} ms  {gbs:7.0f} GB/s")
+        print(f"C={C:2d} S={S:5d} {name:15s} {ms/n:8.3f} ms  {gbs:7.0f} GB/s")
         b.close()
