@@ -331,9 +331,9 @@ static int batch_init(cmhip_batch_t *b)
     HIP_TRY(hipMemsetAsync(b->d_dbg, 0, 64 * sizeof(unsigned long long), b->stream));
     if (d.flags & CMHIP_EQ) {
         HIP_TRY(hipMalloc((void **)&b->d_eq, S * sizeof(EqParam)));
-        HIP_TRY(hipMalloc((void **)&b->d_eqstate, S * sizeof(EqState)));
+        HIP_TRY(hipMalloc((void **)&b->d_eqstate, S * d.channels * sizeof(EqState)));   // per channel
         HIP_TRY(hipMemsetAsync(b->d_eq, 0, S * sizeof(EqParam), b->stream));
-        HIP_TRY(hipMemsetAsync(b->d_eqstate, 0, S * sizeof(EqState), b->stream));
+        HIP_TRY(hipMemsetAsync(b->d_eqstate, 0, S * d.channels * sizeof(EqState), b->stream));
         b->h_eq.assign(S, EqParam{});
     }
     for (int i = 0; i < 2; i++) {
@@ -369,10 +369,6 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     }
     if ((uint64_t)desc->max_frames * desc->channels >= (1ull << 31)) {
         fail(COOLMIC_ERROR_INVAL, "cmhip_batch_new: slot larger than 2^31 samples");
-        return nullptr;
-    }
-    if ((desc->flags & CMHIP_EQ) && desc->channels != 1) {
-        fail(COOLMIC_ERROR_INVAL, "cmhip_batch_new: CMHIP_EQ needs a mono batch");
         return nullptr;
     }
     if (!(desc->flags & (CMHIP_OUT_PCM | CMHIP_OUT_F32 | CMHIP_VU))) {
@@ -544,10 +540,11 @@ extern "C" int cmhip_batch_eq_reset(cmhip_batch_t *b, long stream)
         return fail(COOLMIC_ERROR_INVAL, "eq_reset: stream %ld out of range", stream);
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
+    const size_t per_stream = b->d.channels * sizeof(EqState);
     if (stream < 0)
-        HIP_TRY(hipMemsetAsync(b->d_eqstate, 0, b->d.streams * sizeof(EqState), b->stream));
+        HIP_TRY(hipMemsetAsync(b->d_eqstate, 0, b->d.streams * per_stream, b->stream));
     else
-        HIP_TRY(hipMemsetAsync(b->d_eqstate + stream, 0, sizeof(EqState), b->stream));
+        HIP_TRY(hipMemsetAsync(b->d_eqstate + (size_t)stream * b->d.channels, 0, per_stream, b->stream));
     return COOLMIC_ERROR_NONE;
 }
 
@@ -825,7 +822,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         ev = take_events(b);
         HIP_TRY(hipEventRecord(ev.a, b->stream));
     }
-    if (b->d.flags & CMHIP_EQ) {
+    if ((b->d.flags & CMHIP_EQ) && b->nsec) {        // without sections the plain kernels do the same
         EqArgs a;
         memset(&a, 0, sizeof(a));
         a.in = b->d_in;
@@ -838,6 +835,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.nframes = frames_per_stream ? b->d_nframes : nullptr;
         a.frames = (uint32_t)frames;
         a.streams = b->d.streams;
+        a.channels = b->d.channels;
         a.nsec = b->nsec;
         a.parity = b->parity;
         a.dbg = b->d_dbg;

@@ -80,6 +80,7 @@ struct EqArgs {
     const uint32_t *nframes;
     uint32_t       frames;
     uint32_t       streams;
+    uint32_t       channels;       // every channel of a stream runs the stream's filter, with state of its own
     uint32_t       nsec;           // biquad sections, same for every stream of the batch
     uint32_t       parity;
     uint64_t       stride;

@@ -939,18 +939,10 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------
-// EQ path (mono): int16 -> gain -> x/32768.f -> NSEC biquads (Direct Form I with the
-// fmaf order the oracle fixes) -> float and/or int16 (+VU of the int16 result).
-// The recurrence runs along time, so a lane owns a stream; 64x64 tiles are moved
-// through LDS so that global loads and stores stay whole 128/256-byte rows.
-// k_eq is the plain form (one wave does everything for 64 streams): it serves the filter
-// bypass (0 sections); batches with 1..4 sections run on k_eq_pipe further down, which is
-// ~30x faster on config 3.
+// EQ path: int16 -> channel map -> gain -> x/32768.f -> NSEC biquads (Direct Form I with the
+// fmaf order the oracle fixes) -> float planes and/or int16 (+VU of the int16 result).
 
-constexpr u32 EQ_TT = 64;           // frames per tile
-constexpr u32 EQ_IN_ROW = 33;       // dwords per int16 row (32 + 1 pad: conflict free)
-constexpr u32 EQ_OUT_ROW = 65;      // dwords per float row (64 + 1 pad)
-
+// float -> int16 of the EQ result: round to nearest even, saturate, NaN -> 0 (oracle_f32_to_i16)
 __device__ __forceinline__ int f32_to_i16(float y)
 {
     float v = y * 32768.0f;
@@ -962,137 +954,8 @@ __device__ __forceinline__ int f32_to_i16(float y)
     return (int)v;
 }
 
-template <int NSEC>
-__global__ __launch_bounds__(64) void k_eq(EqArgs a)
-{
-    __shared__ u32 tin[64 * EQ_IN_ROW];
-    __shared__ float tout[64 * EQ_OUT_ROW];
-    const u32 lane = threadIdx.x;
-    const u32 s0 = blockIdx.x * 64u;
-    const u32 s = s0 + lane;
-    const bool live = s < a.streams;
-    const u32 sc = live ? s : a.streams - 1;           // clamped for parameter loads
-
-    const u32 nfr = live ? (a.nframes ? a.nframes[sc] : a.frames) : 0;
-    u32 nmax = nfr;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        nmax = max(nmax, (u32)__shfl_xor((int)nmax, o, 64));
-
-    const StreamParam *p = a.param + sc;
-    const u32 magic = p->magic, shift = p->shift, g2 = p->gain2[0];
-    float cf[NSEC > 0 ? NSEC : 1][5], stt[NSEC > 0 ? NSEC : 1][4];
-#pragma unroll
-    for (int i = 0; i < NSEC; i++) {
-#pragma unroll
-        for (int j = 0; j < 5; j++)
-            cf[i][j] = a.eq[sc].coef[i][j];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            stt[i][j] = a.state[sc].s[i][j];
-    }
-
-    u64 pw = 0, ky = 0;
-    const u64 base = (a.vu && live) ? a.vu[sc].samples[a.parity] : 0;
-
-    for (u32 t0 = 0; t0 < nmax; t0 += EQ_TT) {
-        // ---- load: two stream rows (2 x 128 B) per wave instruction
-        const u32 half = lane >> 5, col = lane & 31u;
-#pragma unroll 4
-        for (u32 r = 0; r < 64; r += 2) {
-            const u32 row = r + half;
-            const u32 rs = s0 + row;
-            const u32 rn = (u32)__shfl((int)nfr, (int)row, 64);
-            u32 v = 0;
-            const u32 f = t0 + 2u * col;
-            if (rs < a.streams && f < rn) {
-                const int16_t *src = a.in + (u64)rs * a.stride + f;
-                v = (f + 1 < rn) ? *reinterpret_cast<const u32 *>(src) : (u32)(uint16_t)src[0];
-            }
-            tin[row * EQ_IN_ROW + col] = v;
-        }
-        __syncthreads();
-
-        // ---- recurrence: this lane walks its own row
-        const u32 cnt = nfr > t0 ? min(nfr - t0, EQ_TT) : 0;
-        for (u32 d = 0; d < 32; d++) {
-            const u32 wv = tin[lane * EQ_IN_ROW + d];
-            u32 ow = 0;
-#pragma unroll
-            for (u32 h = 0; h < 2; h++) {
-                const u32 i = 2 * d + h;
-                const int x = h ? ((int)wv >> 16) : (int)(short)(wv & 0xffffu);
-                int sg;
-                const u32 m = gain_mag(x, g2, magic, shift, sg);
-                const int q = (int)((m ^ (u32)sg) - (u32)sg);
-                float v = q * (1.0f / 32768.0f);
-#pragma unroll
-                for (int e = 0; e < NSEC; e++) {
-                    const float f = __builtin_fmaf(cf[e][2], stt[e][1],
-                                                   __builtin_fmaf(cf[e][1], stt[e][0], cf[e][0] * v));
-                    const float y = __builtin_fmaf(-cf[e][3], stt[e][2],
-                                                   __builtin_fmaf(-cf[e][4], stt[e][3], f));
-                    if (i < cnt) {
-                        stt[e][1] = stt[e][0];
-                        stt[e][0] = v;
-                        stt[e][3] = stt[e][2];
-                        stt[e][2] = y;
-                    }
-                    v = y;
-                }
-                tout[lane * EQ_OUT_ROW + i] = v;
-                const int r16 = f32_to_i16(v);
-                ow |= ((u32)r16 & 0xffffu) << (16u * h);
-                if (i < cnt) {
-                    const u32 am = (u32)(r16 < 0 ? -r16 : r16);
-                    pw += (u64)(am * am);
-                    const u64 kk = make_key(am, base + t0 + i, r16 < 0 ? 1u : 0u);
-                    ky = kk > ky ? kk : ky;
-                }
-            }
-            tin[lane * EQ_IN_ROW + d] = ow;
-        }
-        __syncthreads();
-
-        // ---- store: one stream row per wave instruction (256 B float / 128 B int16)
-        for (u32 r = 0; r < 64; r++) {
-            const u32 rs = s0 + r;
-            const u32 rn = (u32)__shfl((int)nfr, (int)r, 64);
-            if (rs >= a.streams)
-                break;
-            const u32 f = t0 + lane;
-            if (a.f32 && f < rn)
-                a.f32[(u64)rs * a.plane + f] = tout[r * EQ_OUT_ROW + lane];
-            if (a.out && lane < 32) {
-                const u32 f2 = t0 + 2u * lane;
-                const u32 wv = tin[r * EQ_IN_ROW + lane];
-                int16_t *d16 = a.out + (u64)rs * a.stride + f2;
-                if (f2 + 1 < rn)
-                    *reinterpret_cast<u32 *>(d16) = wv;
-                else if (f2 < rn)
-                    d16[0] = (int16_t)(wv & 0xffffu);
-            }
-        }
-        __syncthreads();
-    }
-
-    if (live) {
-#pragma unroll
-        for (int i = 0; i < NSEC; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                a.state[s].s[i][j] = stt[i][j];
-        if (a.vu) {                                   // this lane is the only writer of stream s
-            a.vu[s].samples[a.parity ^ 1u] = base + nfr;
-            a.vu[s].power[0] += pw;
-            if (ky > a.vu[s].key[0])
-                a.vu[s].key[0] = ky;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
-// Pipelined EQ (float output only, 1..4 sections): the fast form of config 3.
+// The pipelined EQ kernel (1..4 sections; config 3 is its mono, float-planes case).
 //
 // The recurrence allows no parallelism along time, so the per-sample work is cut in two:
 //
@@ -1126,7 +989,11 @@ __global__ __launch_bounds__(64) void k_eq(EqArgs a)
 #define CMHIP_EQ_ABL 0            // `make abl`: timing-only builds with one part of the pipeline cut out
 #endif
 
-template <int NSEC, int G, int NSW>
+// Channels: a "row" is one channel of one stream -- every channel runs its stream's filter
+// with state of its own -- and a workgroup takes G / C whole streams (MONO: the 16-byte
+// vector loads and packed stores of config 3; otherwise the T lanes gather their channel's
+// samples with 16-bit loads through the stream's channel map and the S lanes scatter them).
+template <int NSEC, int G, int NSW, bool MONO>
 __global__ __launch_bounds__((((NSEC + 64 / G - 1) / (64 / G)) + G / 8 + NSW) * 64)
 void k_eq_pipe(EqArgs a)
 {
@@ -1144,7 +1011,15 @@ void k_eq_pipe(EqArgs a)
     extern __shared__ float lds[];                // NBUF buffers x 2 slots x EP_TILE floats, then G counts
     u32 *nfr_lds = reinterpret_cast<u32 *>(lds + NBUF * 2 * EP_TILE);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const u32 s0 = blockIdx.x * G;
+    const u32 C = MONO ? 1u : a.channels;
+    const u32 SPG = G / C;                                // whole streams of this workgroup
+    const u32 s0 = blockIdx.x * SPG;
+    // row r of the workgroup: channel r % C of stream s0 + r / C
+    auto row_stream = [&](u32 r, u32 &ch) -> u32 {
+        const u32 q = MONO ? r : r / C;
+        ch = MONO ? 0u : r - q * C;
+        return q < SPG ? s0 + q : 0xffffffffu;            // rows past the last whole stream idle
+    };
 
     const bool is_rec = wave < NRW;
     const bool is_store = wave >= NRW + NTW;              // the S waves
@@ -1155,8 +1030,10 @@ void k_eq_pipe(EqArgs a)
     const u32 sec = wave * SPW + lane / G;
     const bool has_sec = is_rec && sec < (u32)NSEC;
     const u32 row = lane % G;
-    const u32 sl = s0 + row;
+    u32 my_ch;
+    const u32 sl = row_stream(row, my_ch);
     const bool live = sl < a.streams;
+    const u32 sidx = live ? sl * C + my_ch : 0u;           // EqState index of this row
     const u32 my_nfr = live ? (a.nframes ? a.nframes[sl] : a.frames) : 0u;
     if (wave == 0 && lane < G)
         nfr_lds[lane] = my_nfr;
@@ -1172,7 +1049,7 @@ void k_eq_pipe(EqArgs a)
     float d1 = 0, d2 = 0, h1 = 0, h2 = 0;
     if (has_sec && live) {
         const float *c = a.eq[sl].coef[sec];
-        const float *st = a.state[sl].s[sec];
+        const float *st = a.state[sidx].s[sec];
         d1 = -c[3]; d2 = -c[4];
         h1 = st[2]; h2 = st[3];
     }
@@ -1181,9 +1058,12 @@ void k_eq_pipe(EqArgs a)
     const u32 l_r = 8u * tw + lane / 8u;
     const u32 l_c = lane % 8u;
     const u32 l_t8 = l_c * 8u;
-    const u32 l_s = min(s0 + l_r, a.streams - 1);
-    const bool l_live = !is_rec && !is_store && s0 + l_r < a.streams;
-    u32 l_magic = 0, l_shift = 0, l_g2 = 0, l_n = 0;
+    u32 l_ch;
+    const u32 l_stream = row_stream(l_r, l_ch);
+    const u32 l_s = min(l_stream, a.streams - 1);
+    const bool l_live = !is_rec && !is_store && l_stream < a.streams;
+    const u32 l_sidx = l_s * C + l_ch;
+    u32 l_magic = 0, l_shift = 0, l_g2 = 0, l_n = 0, l_m = 0;
     float fc[NSEC][3];                                    // b0 b1 b2 of every section of this row
     float sx1[NSEC], sx2[NSEC];                           // x[t-1], x[t-2] before the next block
 #pragma unroll
@@ -1194,7 +1074,8 @@ void k_eq_pipe(EqArgs a)
     if (!is_rec && !is_store) {
         l_magic = a.param[l_s].magic;
         l_shift = a.param[l_s].shift;
-        l_g2 = a.param[l_s].gain2[0];
+        l_g2 = a.param[l_s].gain2[l_ch];
+        l_m = MONO ? 0u : a.param[l_s].chmap[l_ch];       // the input channel this row reads
         l_n = nfr_lds[l_r];
         if (l_live) {
 #pragma unroll
@@ -1207,7 +1088,7 @@ void k_eq_pipe(EqArgs a)
                 const float sc = k == 0 ? (1.0f / 32768.0f) : 1.0f;
                 const float si = k == 0 ? 32768.0f : 1.0f;
                 const float *c = a.eq[l_s].coef[k];
-                const float *st = a.state[l_s].s[k];
+                const float *st = a.state[l_sidx].s[k];
                 fc[k][0] = c[0] * sc; fc[k][1] = c[1] * sc; fc[k][2] = c[2] * sc;
                 sx1[k] = st[0] * si; sx2[k] = st[1] * si;
             }
@@ -1223,12 +1104,20 @@ void k_eq_pipe(EqArgs a)
     // global memory inside the loop, so the compiler can wait with vmcnt(1) for the older
     // block instead of draining the queue; the stores have a wave of their own.
     const int16_t *l_src = a.in + (u64)l_s * a.stride;
-    const u32 l_last = (u32)a.stride - 8u;
+    const u32 l_last = (u32)a.stride - (MONO ? 8u : 1u);
     auto fetch = [&](u32 b) -> u32x4 {
         const u32 f0 = b * EP_TB + l_t8;
         if (CMHIP_EQ_ABL & 2)
             return u32x4{f0, f0 * 3u, f0 * 5u, f0 * 7u};
-        return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(l_src + min(f0, l_last)));
+        if constexpr (MONO) {
+            return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(l_src + min(f0, l_last)));
+        } else {
+            u32 h[8];                                     // frames f0..f0+7 of input channel l_m
+#pragma unroll
+            for (u32 k = 0; k < 8; k++)
+                h[k] = *reinterpret_cast<const uint16_t *>(l_src + min((f0 + k) * C + l_m, l_last));
+            return u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+        }
     };
     u32x4 wa = {0, 0, 0, 0}, wb = {0, 0, 0, 0};           // blocks of even / odd steps
     if (!is_rec && !is_store) {
@@ -1447,12 +1336,16 @@ void k_eq_pipe(EqArgs a)
     static_assert((G / RPI) % NSW == 0, "row slots must divide among the S waves");
     constexpr u32 NSL = G / RPI / NSW;                    // row slots of one S wave
     u64 vpw[NSL], vky[NSL], vbase[NSL];
+    u32 v_stream[NSL], v_ch[NSL];                         // stream (or none) and channel of the slot's row
 #pragma unroll
     for (u32 i = 0; i < NSL; i++) {
         vpw[i] = vky[i] = vbase[i] = 0;
         const u32 r = RPI * (i * NSW + sw) + lane / SPR;
-        if (is_store && a.vu && s0 + r < a.streams)
-            vbase[i] = a.vu[s0 + r].samples[a.parity];
+        v_stream[i] = row_stream(r, v_ch[i]);
+        if (v_stream[i] >= a.streams)
+            v_stream[i] = 0xffffffffu;
+        if (is_store && a.vu && v_stream[i] != 0xffffffffu)
+            vbase[i] = a.vu[v_stream[i]].samples[a.parity];
     }
     auto s_step = [&](const u32 step) {
         if (!(CMHIP_EQ_ABL & 1)) {
@@ -1470,8 +1363,11 @@ void k_eq_pipe(EqArgs a)
                     const u32 n = nfr_lds[r];
                     const float4 v = *reinterpret_cast<const float4 *>(Y + r * EP_ROW + t4);
                     const float e[4] = {v.x, v.y, v.z, v.w};
+                    const u32 vs_ = v_stream[i], vc_ = v_ch[i];
+                    if (vs_ == 0xffffffffu)
+                        continue;
                     if (a.f32) {
-                        float *dstf = a.f32 + (u64)(s0 + r) * a.plane + f0;
+                        float *dstf = a.f32 + ((u64)vs_ * C + vc_) * a.plane + f0;
                         if (f0 + 4u <= n) {
                             typedef float f32x4 __attribute__((ext_vector_type(4)));
                             const f32x4 vv = {v.x, v.y, v.z, v.w};
@@ -1488,15 +1384,23 @@ void k_eq_pipe(EqArgs a)
                             q[j] = f32_to_i16(e[j]);
                         const bool whole = __all(f0 + 4u <= n);     // no stream ends inside these
                         if (a.out) {
-                            int16_t *d16 = a.out + (u64)(s0 + r) * a.stride + f0;
-                            if (f0 + 4u <= n) {
-                                typedef u32 u32x2 __attribute__((ext_vector_type(2)));
-                                const u32x2 pk = {((u32)q[0] & 0xffffu) | ((u32)q[1] << 16),
-                                                  ((u32)q[2] & 0xffffu) | ((u32)q[3] << 16)};
-                                __builtin_nontemporal_store(pk, reinterpret_cast<u32x2 *>(d16));
-                            } else if (f0 < n) {
-                                for (u32 j = 0; j < n - f0; j++)
-                                    d16[j] = (int16_t)q[j];
+                            if constexpr (MONO) {
+                                int16_t *d16 = a.out + (u64)vs_ * a.stride + f0;
+                                if (f0 + 4u <= n) {
+                                    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+                                    const u32x2 pk = {((u32)q[0] & 0xffffu) | ((u32)q[1] << 16),
+                                                      ((u32)q[2] & 0xffffu) | ((u32)q[3] << 16)};
+                                    __builtin_nontemporal_store(pk, reinterpret_cast<u32x2 *>(d16));
+                                } else if (f0 < n) {
+                                    for (u32 j = 0; j < n - f0; j++)
+                                        d16[j] = (int16_t)q[j];
+                                }
+                            } else {                      // interleaved result: this row's channel
+                                int16_t *d16 = a.out + (u64)vs_ * a.stride + (u64)f0 * C + vc_;
+#pragma unroll
+                                for (u32 j = 0; j < 4; j++)
+                                    if (f0 + j < n)
+                                        d16[j * C] = (int16_t)q[j];
                             }
                         }
                         if (a.vu) {
@@ -1521,7 +1425,7 @@ void k_eq_pipe(EqArgs a)
 #pragma unroll
                             for (u32 j = 1; j < 4; j++)
                                 qm = jm == j ? q[j] : qm;
-                            const u64 kk = make_key(m, vbase[i] + f0 + jm, qm < 0 ? 1u : 0u);
+                            const u64 kk = make_key(m, vbase[i] + (u64)(f0 + jm) * C + vc_, qm < 0 ? 1u : 0u);
                             vky[i] = kk > vky[i] ? kk : vky[i];
                         }
                     }
@@ -1568,12 +1472,13 @@ void k_eq_pipe(EqArgs a)
                     ky = ok > ky ? ok : ky;
                 }
                 const u32 r = RPI * (i * NSW + sw) + lane / SPR;
-                if (lane % SPR == 0 && s0 + r < a.streams) {
-                    VuState *vs = a.vu + s0 + r;
-                    vs->samples[a.parity ^ 1u] = vbase[i] + nfr_lds[r];
-                    vs->power[0] += pw;
-                    if (ky > vs->key[0])
-                        vs->key[0] = ky;
+                if (lane % SPR == 0 && v_stream[i] != 0xffffffffu) {
+                    VuState *vs = a.vu + v_stream[i];
+                    if (v_ch[i] == 0)
+                        vs->samples[a.parity ^ 1u] = vbase[i] + (u64)nfr_lds[r] * C;
+                    vs->power[v_ch[i]] += pw;
+                    if (ky > vs->key[v_ch[i]])
+                        vs->key[v_ch[i]] = ky;
                 }
             }
         }
@@ -1583,9 +1488,9 @@ void k_eq_pipe(EqArgs a)
             EQ_STEP(t_step(wb, step + 1));
         }
         if (has1)
-            a.state[l_s].s[0][0] = keep1 * (1.0f / 32768.0f);
+            a.state[l_sidx].s[0][0] = keep1 * (1.0f / 32768.0f);
         if (has2)
-            a.state[l_s].s[0][1] = keep2 * (1.0f / 32768.0f);
+            a.state[l_sidx].s[0][1] = keep2 * (1.0f / 32768.0f);
     }
 #undef EQ_STEP
 #ifdef CMHIP_EQ_STAMPS
@@ -1604,11 +1509,11 @@ void k_eq_pipe(EqArgs a)
     // state for the next launch.  y1/y2 of section k are also the x1/x2 of section k+1
     // (its input is this section's output); section 0's x1/x2 were written by the T lanes.
     if (has_sec && live) {
-        float *st = a.state[sl].s[sec];
+        float *st = a.state[sidx].s[sec];
         st[2] = h1;
         st[3] = h2;
         if (sec + 1u < (u32)NSEC) {
-            float *sn = a.state[sl].s[sec + 1u];
+            float *sn = a.state[sidx].s[sec + 1u];
             if (my_nfr >= 2u) {
                 sn[0] = h1;
                 sn[1] = h2;
@@ -1626,47 +1531,45 @@ static constexpr size_t eq_pipe_lds_bytes()
     return ((size_t)(2 * NSEC) * 2 * G * (64 + 4)) * sizeof(float) + G * sizeof(u32);
 }
 
-template <int NSEC, int G, int NSW>
+template <int NSEC, int G, int NSW, bool MONO>
 static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
 {
     constexpr size_t lds_bytes = eq_pipe_lds_bytes<NSEC, G>();
     static_assert(lds_bytes <= 160 * 1024, "tiles of a workgroup must fit the LDS");
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G, NSW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G, NSW, MONO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess)
             return e;
         configured = true;
     }
     constexpr int SPW = 64 / G, NRW = (NSEC + SPW - 1) / SPW;
-    hipLaunchKernelGGL((k_eq_pipe<NSEC, G, NSW>), dim3((a.streams + G - 1) / G),
+    const u32 spg = MONO ? G : G / a.channels;            // whole streams per workgroup
+    hipLaunchKernelGGL((k_eq_pipe<NSEC, G, NSW, MONO>), dim3((a.streams + spg - 1) / spg),
                        dim3((NRW + G / 8 + NSW) * 64), lds_bytes, st, a);
     return hipGetLastError();
 }
 
+// 32 rows per workgroup: all 256 CUs at 8192 mono streams, and what the LDS holds for four
+// sections (8 and 16 rows with several workgroups per CU measured the same or slower)
 template <int NSEC>
 static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st)
 {
-    const char *e = getenv("CMHIP_EQ_G");                 // tuning knob: streams per workgroup
-    const int g = e ? atoi(e) : 32;                       // 32: all 256 CUs at 8192 streams
     // the int16 conversion and the VU window are per-sample work of the S waves: more of them
     const bool heavy = a.out || a.vu;
-    if (g == 16)
-        return heavy ? launch_eq_pipe<NSEC, 16, 4>(a, st) : launch_eq_pipe<NSEC, 16, 1>(a, st);
-    if (g == 8)
-        return heavy ? launch_eq_pipe<NSEC, 8, 2>(a, st) : launch_eq_pipe<NSEC, 8, 1>(a, st);
-    return heavy ? launch_eq_pipe<NSEC, 32, 4>(a, st) : launch_eq_pipe<NSEC, 32, 1>(a, st);
+    if (a.channels == 1)
+        return heavy ? launch_eq_pipe<NSEC, 32, 4, true>(a, st) : launch_eq_pipe<NSEC, 32, 1, true>(a, st);
+    return heavy ? launch_eq_pipe<NSEC, 32, 4, false>(a, st) : launch_eq_pipe<NSEC, 32, 1, false>(a, st);
 }
 
 hipError_t launch_eq(const EqArgs &a, hipStream_t st)
 {
     if (a.streams == 0 || a.frames == 0 || !(a.f32 || a.out || a.vu))
         return hipSuccess;
-    switch (a.nsec) {
-    case 0:                                               // filter bypass: gain and conversion only
-        hipLaunchKernelGGL(k_eq<0>, dim3((a.streams + 63) / 64), dim3(64), 0, st, a);
-        return hipGetLastError();
+    if (a.channels == 0 || a.channels > MAX_CH)
+        return hipErrorInvalidValue;
+    switch (a.nsec) {                                     // (0 sections: the caller uses launch_run)
     case 1: return launch_eq_pipe_g<1>(a, st);            // the pipelined kernel, whatever is asked
     case 2: return launch_eq_pipe_g<2>(a, st);            // for (float planes, int16, VU of it)
     case 3: return launch_eq_pipe_g<3>(a, st);

@@ -190,3 +190,71 @@ def test_eq_pipelined_int16_and_vu_only(gpu, oracle, gain_mode, inplace):
         if rc_o == 0:
             assert r_g.as_dict() == of.vu_result_dict(r_o), (gain_mode, s)
     b.close()
+
+
+@pytest.mark.parametrize("C", [2, 3, 6, 16])
+def test_eq_on_multichannel_streams(gpu, oracle, C):
+    """every channel of a stream runs the stream's filter with state of its own, after the
+    channel map and its own gain: float planes, interleaved int16 result, per-channel VU;
+    expected values are the mono oracle run once per channel"""
+    cm = gpu
+    rng = np.random.default_rng(31 + C)
+    S, T, nsec = 37, 300, 3
+    coef = cm.eq3(48000.0)
+    for flags in (cm.EQ | cm.OUT_F32 | cm.OUT_PCM | cm.VU, cm.EQ | cm.OUT_PCM | cm.VU | cm.INPLACE,
+                  cm.EQ | cm.OUT_F32):
+        b = cm.Batch(S, C, T, flags=flags)
+        assert b.set_eq(-1, coef) == 0
+        gains, maps = [], []
+        for s in range(S):
+            g = None if s % 4 == 0 else (int(rng.integers(1, 3000)), [int(v) for v in rng.integers(0, 4000, C)])
+            m = None if s % 3 == 0 else [int(v) for v in rng.integers(0, C, C)]
+            if g:
+                assert b.set_gain(s, C, g[0], g[1]) == 0
+            if m:
+                assert b.set_chmap(s, m) == 0
+            gains.append(g)
+            maps.append(m)
+        all_lens = []
+        for k in range(2):
+            lens = [int(v) for v in rng.integers(0, T + 1, S)]
+            lens[0], lens[1], lens[2], lens[3] = T, k, 2, 64
+            all_lens.append(lens)
+        blocks = [[rng.integers(-32768, 32768, all_lens[k][s] * C).astype(np.int16) for k in range(2)]
+                  for s in range(S)]
+        got = [[None] * 2 for _ in range(S)]
+        for k in range(2):
+            for s in range(S):
+                if all_lens[k][s]:
+                    b.upload(s, blocks[s][k])
+            b.run(T, frames_per_stream=all_lens[k])
+            for s in range(S):
+                n = all_lens[k][s]
+                pcm = b.download(s, n) if (flags & cm.OUT_PCM) else None
+                planes = [b.download_f32(s, c, n) for c in range(C)] if (flags & cm.OUT_F32) else None
+                got[s][k] = (pcm, planes)
+        for s in range(S):
+            per_ch = []
+            for c in range(C):
+                src = c if maps[s] is None else maps[s][c]
+                chans = [blocks[s][k].reshape(-1, C)[:, src].copy() for k in range(2)]
+                ga = None if gains[s] is None else (1, gains[s][0], [gains[s][1][c]])
+                per_ch.append(_oracle_eq(oracle, coef, nsec, ga, chans))
+            v = oracle.vu_new(C)
+            for k in range(2):
+                n = all_lens[k][s]
+                want_i = np.stack([per_ch[c][k][1] for c in range(C)], axis=1).reshape(-1) if n else np.zeros(0, np.int16)
+                pcm, planes = got[s][k]
+                if pcm is not None:
+                    assert np.array_equal(pcm, want_i), (C, flags, s, k)
+                if planes is not None:
+                    for c in range(C):
+                        assert np.array_equal(planes[c].view(np.uint32), per_ch[c][k][0].view(np.uint32)), (C, s, k, c)
+                oracle.vu_accumulate(v, want_i)
+            if flags & cm.VU:
+                rc_o, r_o = oracle.vu_result(v)
+                rc_g, r_g = b.vu_result(s)
+                assert rc_g == rc_o, (C, s)
+                if rc_o == 0:
+                    assert r_g.as_dict() == of.vu_result_dict(r_o), (C, flags, s)
+        b.close()
