@@ -51,6 +51,11 @@ int                 coolmic_group_set_master_gain(coolmic_group_t *self, unsigne
                                                   const uint16_t *gain);
 int                 coolmic_group_set_channel_map(coolmic_group_t *self, unsigned int slot,
                                                   const uint8_t *map);
+/* equaliser as coolmic_transform_set_eq().  The number of sections is one for the whole
+ * group: slot -1 sets every stream (and may change the count), a slot >= 0 only replaces
+ * that stream's coefficients and must keep the count (else COOLMIC_ERROR_INVAL). */
+int                 coolmic_group_set_eq(coolmic_group_t *self, int slot, unsigned int sections,
+                                         const float *coef);
 
 /* transformed PCM of one stream; keeps the group alive while it lives */
 coolmic_iohandle_t *coolmic_group_get_iohandle(coolmic_group_t *self, unsigned int slot);

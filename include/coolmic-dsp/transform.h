@@ -53,6 +53,16 @@ int                    coolmic_transform_set_master_gain(coolmic_transform_t *se
 int                    coolmic_transform_set_channel_map(coolmic_transform_t *self,
                                                          const uint8_t *map);
 
+/* IIR equaliser after map and gain: `sections` (0..4) biquads of five floats each,
+ * {b0, b1, b2, a1, a2} normalised to a0 = 1, evaluated per channel in Direct Form I on
+ * x/32768.f with state of its own per channel; the result goes back to int16 (round to
+ * nearest even, saturated).  0 sections switches the filter off and clears its state; new
+ * coefficients keep the state.  COOLMIC_ERROR_INVAL for more than 4 sections or a NULL
+ * coefficient pointer. */
+#define COOLMIC_DSP_TRANSFORM_MAX_EQ_SECTIONS 4
+int                    coolmic_transform_set_eq(coolmic_transform_t *self, unsigned int sections,
+                                                const float *coef);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,7 +40,7 @@ typedef struct cmhip_batch cmhip_batch_t;
 #define CMHIP_OUT_F32      0x0002u   /* planar float copy of the transformed PCM */
 #define CMHIP_VU           0x0004u   /* accumulate the VU meters */
 #define CMHIP_INPLACE      0x0008u   /* PCM output overwrites the input slots (as the reference does) */
-#define CMHIP_EQ           0x0010u   /* biquad EQ after the gain (mono batches; float and/or int16 out) */
+#define CMHIP_EQ           0x0010u   /* biquad EQ after map and gain, every channel with state of its own */
 
 /* synthetic inputs generated on the device */
 #define CMHIP_GEN_NULL     0         /* zeros, as snddev "null" */
@@ -76,7 +76,9 @@ int cmhip_batch_set_gain(cmhip_batch_t *b, long stream, unsigned int channels, u
 /* out channel c reads input channel map[c]; NULL = identity */
 int cmhip_batch_set_chmap(cmhip_batch_t *b, long stream, const uint8_t *map);
 /* nsec biquads, 5 floats each {b0,b1,b2,a1,a2} (a0-normalised); nsec 0 = bypass.
- * Filter state is kept per stream across runs; cmhip_batch_eq_reset() zeroes it. */
+ * Every channel of a stream runs the stream's filter with state of its own, kept across
+ * runs; cmhip_batch_eq_reset() zeroes it.  The section count is one for the whole batch:
+ * stream -1 sets all streams (and may change the count), a stream >= 0 must keep it. */
 int cmhip_batch_set_eq(cmhip_batch_t *b, long stream, unsigned int nsec, const float *coef);
 int cmhip_batch_eq_reset(cmhip_batch_t *b, long stream);
 /* RBJ designs on the host in double, cast to float: kind 0 low shelf, 1 peaking, 2 high

@@ -133,6 +133,7 @@ SIGNATURES = {
     "coolmic_transform_get_iohandle": (_vp, [_vp]),
     "coolmic_transform_set_master_gain": (C.c_int, [_vp, C.c_uint, C.c_uint16, _P(C.c_uint16)]),
     "coolmic_transform_set_channel_map": (C.c_int, [_vp, _vp]),
+    "coolmic_transform_set_eq": (C.c_int, [_vp, C.c_uint, _vp]),
     # include/coolmic-dsp/vumeter.h
     "coolmic_vumeter_new": (_vp, [C.c_char_p, _vp, C.c_uint32, C.c_uint]),
     "coolmic_vumeter_reset": (C.c_int, [_vp]),
@@ -157,6 +158,7 @@ SIGNATURES = {
     "coolmic_group_add_stream": (C.c_int, [_vp, _vp]),
     "coolmic_group_set_master_gain": (C.c_int, [_vp, C.c_uint, C.c_uint, C.c_uint16, _P(C.c_uint16)]),
     "coolmic_group_set_channel_map": (C.c_int, [_vp, C.c_uint, _vp]),
+    "coolmic_group_set_eq": (C.c_int, [_vp, C.c_int, C.c_uint, _vp]),
     "coolmic_group_get_iohandle": (_vp, [_vp, C.c_uint]),
     "coolmic_group_pump": (C.c_int, [_vp]),
     "coolmic_group_vumeter_result": (C.c_int, [_vp, C.c_uint, _P(VuResult)]),
@@ -514,6 +516,13 @@ class Transform:
         m = np.asarray(cmap, dtype=np.uint8)
         return lib.coolmic_transform_set_channel_map(self.ptr, m.ctypes.data)
 
+    def set_eq(self, coef):
+        """coef: 5 floats per section (b0 b1 b2 a1 a2), or None / empty to switch the filter off"""
+        if coef is None or len(coef) == 0:
+            return lib.coolmic_transform_set_eq(self.ptr, 0, None)
+        c = np.ascontiguousarray(coef, dtype=np.float32)
+        return lib.coolmic_transform_set_eq(self.ptr, c.size // 5, c.ctypes.data)
+
     def refcount(self):
         return lib.coolmic_ro_refcount(self.ptr)
 
@@ -590,6 +599,12 @@ class Group:
             return lib.coolmic_group_set_channel_map(self.ptr, slot, None)
         m = np.asarray(cmap, dtype=np.uint8)
         return lib.coolmic_group_set_channel_map(self.ptr, slot, m.ctypes.data)
+
+    def set_eq(self, slot, coef):
+        if coef is None or len(coef) == 0:
+            return lib.coolmic_group_set_eq(self.ptr, slot, 0, None)
+        c = np.ascontiguousarray(coef, dtype=np.float32)
+        return lib.coolmic_group_set_eq(self.ptr, slot, c.size // 5, c.ctypes.data)
 
     def get_iohandle(self, slot):
         return IoHandle(lib.coolmic_group_get_iohandle(self.ptr, slot))

@@ -79,7 +79,7 @@ extern "C" coolmic_group_t *coolmic_group_new(const char *name, igloo_ro_t assoc
     d.channels = channels;
     d.rate = (unsigned int)rate;
     d.max_frames = block_frames;
-    d.flags = CMHIP_OUT_PCM | CMHIP_VU;
+    d.flags = CMHIP_OUT_PCM | CMHIP_VU | CMHIP_EQ;     // the equaliser is off until coolmic_group_set_eq()
     g->batch = cmhip_batch_new(&d);
     if (!g->batch) {
         coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_NOSYS,
@@ -143,6 +143,19 @@ extern "C" int coolmic_group_set_channel_map(coolmic_group_t *self, unsigned int
     if (slot >= self->streams->size())
         return COOLMIC_ERROR_INVAL;
     return cmhip_batch_set_chmap(self->batch, (long)slot, map);
+}
+
+extern "C" int coolmic_group_set_eq(coolmic_group_t *self, int slot, unsigned int sections,
+                                    const float *coef)
+{
+    if (!self)
+        return COOLMIC_ERROR_FAULT;
+    if (slot < -1 || (slot >= 0 && (size_t)slot >= self->streams->size()))
+        return COOLMIC_ERROR_INVAL;
+    const int rc = cmhip_batch_set_eq(self->batch, (long)slot, sections, coef);
+    if (rc == COOLMIC_ERROR_NONE && sections == 0)
+        return cmhip_batch_eq_reset(self->batch, -1);
+    return rc;
 }
 
 extern "C" int coolmic_group_pump(coolmic_group_t *self)

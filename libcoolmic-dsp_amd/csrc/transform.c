@@ -4,9 +4,9 @@
  * The host keeps exactly the reference's framing: a read is cut to whole frames,
  * a carried partial frame goes first, upstream is asked once, the new partial
  * frame is kept for next time (ref: src/transform.c:126-165).  The arithmetic of
- * the whole frames -- channel map, gain, saturation -- runs on the GPU through a
- * one-stream cmhip batch; nothing is computed on the CPU.  Only the reference's own
- * early-out (gain disabled, ref: src/transform.c:107-108) skips the device.
+ * the whole frames -- channel map, gain, saturation, equaliser -- runs on the GPU
+ * through a one-stream cmhip batch; nothing is computed on the CPU.  Only the reference's
+ * own early-out (gain disabled, ref: src/transform.c:107-108) skips the device.
  *
  * Parameter setters may be called from another thread while the worker reads
  * (ref: src/simple.c:759-766); they publish under a mutex and take effect at the
@@ -35,6 +35,9 @@ struct coolmic_transform {
     uint16_t gain[COOLMIC_DSP_TRANSFORM_MAX_CHANNELS];
     uint8_t chmap[COOLMIC_DSP_TRANSFORM_MAX_CHANNELS];
     int map_identity;
+    unsigned int eq_sections;          /* 0: no equaliser */
+    float eq_coef[5 * COOLMIC_DSP_TRANSFORM_MAX_EQ_SECTIONS];
+    int eq_clear;                      /* filter state is to be zeroed before the next block */
     int dirty;                         /* device copy is stale */
 
     cmhip_batch_t *dev;                /* created at the first read that needs it */
@@ -87,18 +90,24 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
 {
     uint16_t scale, gain[COOLMIC_DSP_TRANSFORM_MAX_CHANNELS];
     uint8_t chmap[COOLMIC_DSP_TRANSFORM_MAX_CHANNELS];
-    int identity, dirty;
+    float eq_coef[5 * COOLMIC_DSP_TRANSFORM_MAX_EQ_SECTIONS];
+    unsigned int eq_sections;
+    int identity, dirty, eq_clear;
 
     pthread_mutex_lock(&t->lock);
     scale = t->scale;
     memcpy(gain, t->gain, sizeof(gain));
     memcpy(chmap, t->chmap, sizeof(chmap));
     identity = t->map_identity;
+    eq_sections = t->eq_sections;
+    memcpy(eq_coef, t->eq_coef, sizeof(eq_coef));
+    eq_clear = t->eq_clear;
+    t->eq_clear = 0;
     dirty = t->dirty;
     t->dirty = 0;
     pthread_mutex_unlock(&t->lock);
 
-    if (scale == 0 && identity)
+    if (scale == 0 && identity && eq_sections == 0)
         return 0;                      /* nothing to do, exactly as the reference */
 
     if (t->dev == NULL) {
@@ -109,7 +118,7 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
         d.channels = t->channels;
         d.rate = (unsigned int)t->rate;
         d.max_frames = TRANSFORM_SLICE_FRAMES;
-        d.flags = CMHIP_OUT_PCM | CMHIP_INPLACE;
+        d.flags = CMHIP_OUT_PCM | CMHIP_INPLACE | CMHIP_EQ;
         t->dev = cmhip_batch_new(&d);
         if (t->dev == NULL) {
             coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_NOSYS,
@@ -123,6 +132,10 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
         int rc = cmhip_batch_set_gain(t->dev, 0, scale ? t->channels : 0, scale, gain);
         if (rc == COOLMIC_ERROR_NONE)
             rc = cmhip_batch_set_chmap(t->dev, 0, identity ? NULL : chmap);
+        if (rc == COOLMIC_ERROR_NONE)
+            rc = cmhip_batch_set_eq(t->dev, -1, eq_sections, eq_sections ? eq_coef : NULL);
+        if (rc == COOLMIC_ERROR_NONE && eq_clear)
+            rc = cmhip_batch_eq_reset(t->dev, -1);
         if (rc != COOLMIC_ERROR_NONE) {
             coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, rc, "parameter upload failed: %s",
                                 cmhip_last_error());
@@ -260,6 +273,24 @@ int coolmic_transform_set_channel_map(coolmic_transform_t *self, const uint8_t *
             identity = 0;
     }
     self->map_identity = identity;
+    self->dirty = 1;
+    pthread_mutex_unlock(&self->lock);
+    return COOLMIC_ERROR_NONE;
+}
+
+int coolmic_transform_set_eq(coolmic_transform_t *self, unsigned int sections, const float *coef)
+{
+    if (self == NULL)
+        return COOLMIC_ERROR_FAULT;
+    if (sections > COOLMIC_DSP_TRANSFORM_MAX_EQ_SECTIONS || (sections && coef == NULL))
+        return COOLMIC_ERROR_INVAL;
+
+    pthread_mutex_lock(&self->lock);
+    if (sections)
+        memcpy(self->eq_coef, coef, sizeof(float) * 5u * sections);
+    else
+        self->eq_clear = 1;            /* off: the next filter starts from silence */
+    self->eq_sections = sections;
     self->dirty = 1;
     pthread_mutex_unlock(&self->lock);
     return COOLMIC_ERROR_NONE;

@@ -169,3 +169,62 @@ def test_product_wiring_with_tee(gpu, oracle):
     assert rc == 0 and r.as_dict() == of.vu_result_dict(ro)
     for o in (enc_in, vu, tee, tr):
         o.unref()
+
+
+def _eq_expect(oracle, cm, x, C, coef, scale, gains, cmap):
+    """per channel: map -> gain -> the mono oracle filter; interleaved int16 back"""
+    q = (of.Biquad * 3)()
+    for i in range(3):
+        q[i].b0, q[i].b1, q[i].b2, q[i].a1, q[i].a2 = [float(v) for v in coef[5 * i:5 * i + 5]]
+    frames = x.size // C
+    out = np.empty((frames, C), dtype=np.int16)
+    for c in range(C):
+        src = c if cmap is None else cmap[c]
+        rc, g = oracle.gain(1, 1, scale, [gains[c]])
+        assert rc == 0
+        st = np.zeros(12, dtype=np.float32)
+        _, oi = oracle.eq_run_mono(g, q, 3, st, x.reshape(-1, C)[:, src].copy())
+        out[:, c] = oi
+    return out.reshape(-1)
+
+
+def test_transform_equaliser_behind_the_handle(gpu, oracle):
+    """coolmic_transform_set_eq(): the IIR of the transform stage behind the pull API -- a
+    stereo stream read in odd pieces (every read is a launch of its own, the filter state
+    carries over), then the filter switched off in mid-stream"""
+    cm = gpu
+    C, frames = 2, 30000
+    x = oracle.lcg(77, frames * C)
+    coef = cm.eq3(48000.0)
+    tr = cm.Transform(48000, C)
+    src = cm.IoHandle.from_bytes(x.tobytes(), chunk=1500)
+    assert tr.attach(src) == 0
+    src.unref()
+    h = tr.get_iohandle()
+    assert tr.set_master_gain(2, 1000, [800, 1100]) == 0
+    assert tr.set_channel_map([1, 0]) == 0
+    assert tr.set_eq(coef) == 0
+    assert tr.set_eq(np.zeros(25, np.float32)) == cm.ERROR_INVAL      # five sections: too many
+    got = b""
+    first = 20000 * 2 * C                       # bytes with the filter on
+    sizes = [4096, 10, 2 * C * 333, 65536, 2 * C]
+    i = 0
+    while len(got) < first:
+        n, data = h.read(min(sizes[i % len(sizes)], first - len(got)))
+        i += 1
+        assert n > 0
+        got += data
+    assert tr.set_eq(None) == 0
+    while True:
+        n, data = h.read(8192)
+        if n <= 0:
+            break
+        got += data
+    assert len(got) == x.nbytes
+    res = np.frombuffer(got, np.int16)
+    want_eq = _eq_expect(oracle, cm, x[: 20000 * C], C, coef, 1000, [800, 1100], [1, 0])
+    assert np.array_equal(res[: 20000 * C], want_eq)
+    _, g = oracle.gain(C, 2, 1000, [800, 1100])
+    want_plain = oracle.gain_apply(g, oracle.chmap([1, 0], x[20000 * C:], C), C)
+    assert np.array_equal(res[20000 * C:], want_plain)
+    h.unref(); tr.unref()

@@ -549,8 +549,6 @@ def test_batch_api_error_paths(gpu):
     with pytest.raises(cm.CoolmicError):
         cm.Batch(1, 2, 64, flags=0)
     with pytest.raises(cm.CoolmicError):
-        cm.Batch(1, 2, 64, flags=cm.EQ | cm.OUT_F32)          # EQ needs mono
-    with pytest.raises(cm.CoolmicError):
         cm.Batch(1, 1, 64, device=99)
     b = cm.Batch(2, 2, 64, flags=cm.OUT_PCM | cm.VU)
     assert b.set_gain(2, 2, 1000, [1, 1]) == cm.ERROR_INVAL       # stream out of range
