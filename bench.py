@@ -258,6 +258,36 @@ def main():
                           "Msamples_per_s_kernel": round(samples_per_step_rank / (ms / n * 1e-3) / 1e6, 1),
                           "algorithmic_bytes_per_sample": 2}
 
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "c2":
+        # the other kernels of the path, kernel time only: never part of `value`
+        other = {}
+        try:
+            for name, (s_, c_, t_, fl, bps_, eqz) in {
+                    "c3_eq_float_planes": (8192, 1, 65536, cm.EQ | cm.OUT_F32, 6, True),
+                    "eq_stereo_int16_vu": (4096, 2, 65536, cm.EQ | cm.OUT_PCM | cm.VU, 4, True),
+                    "six_channels_pcm_vu": (2730, 6, 16384, cm.OUT_PCM | cm.VU, 4, False)}.items():
+                o = cm.Batch(s_, c_, t_, flags=fl, device=local_rank)
+                o.set_gain(-1, 1, 1000, [900])
+                if eqz:
+                    o.set_eq(-1, cm.eq3(48000.0))
+                o.generate(cm.GEN_NOISE, 12345, t_)
+                for _ in range(2):
+                    o.run(t_)
+                o.sync()
+                o.timing(True)
+                o.timing_read()
+                for _ in range(5):
+                    o.run(t_)
+                ms, n = o.timing_read()
+                o.close()
+                gbs = s_ * c_ * t_ * bps_ / (ms / n * 1e-3) / 1e9
+                other[name] = {"streams": s_, "channels": c_, "frames": t_, "kernel_avg_ms": round(ms / n, 4),
+                               "algorithmic_bytes_per_sample": bps_, "achieved_GBs": round(gbs, 1),
+                               "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
+        except Exception as e:
+            other["error"] = str(e)
+        out["other_kernels"] = other
+
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.workload, Cn)
 
