@@ -173,6 +173,13 @@ def test_set_master_gain_rules(cm):
     assert st.set_channel_map([1, 0]) == 0
     assert st.set_channel_map([0, 2]) == cm.ERROR_INVAL
     assert st.set_channel_map(None) == 0
+    # the equaliser setter (an addition): argument rules only, no device needed
+    assert cm.lib.coolmic_transform_set_eq(None, 0, None) == cm.ERROR_FAULT
+    assert st.set_eq(np.zeros(15, np.float32)) == 0
+    assert st.set_eq(np.zeros(20, np.float32)) == 0
+    assert st.set_eq(np.zeros(25, np.float32)) == cm.ERROR_INVAL       # more than four sections
+    assert cm.lib.coolmic_transform_set_eq(st.ptr, 2, None) == cm.ERROR_INVAL
+    assert st.set_eq(None) == 0
     st.unref(); mono.unref()
 
 
