@@ -172,7 +172,10 @@ def main():
     kern_avg_ms = kern_ms / max(launches, 1)
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    # HBM bytes per launch from the PMC passes of tools/hbm_pmc.sh, kept per workload
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
+    if not os.path.exists(pmc_path):
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
