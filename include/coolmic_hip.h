@@ -41,6 +41,8 @@ typedef struct cmhip_batch cmhip_batch_t;
 #define CMHIP_VU           0x0004u   /* accumulate the VU meters */
 #define CMHIP_INPLACE      0x0008u   /* PCM output overwrites the input slots (as the reference does) */
 #define CMHIP_EQ           0x0010u   /* biquad EQ after map and gain, every channel with state of its own */
+#define CMHIP_HOSTPCM      0x0020u   /* PCM slots in pinned host memory the kernels access directly (zero copy):
+                                      * for small batches fed block by block, e.g. the per-stream stages */
 
 /* synthetic inputs generated on the device */
 #define CMHIP_GEN_NULL     0         /* zeros, as snddev "null" */

@@ -29,7 +29,7 @@ ssize_t = C.c_ssize_t
 ERROR_NONE, ERROR_GENERIC, ERROR_NOSYS, ERROR_FAULT = 0, -1, -8, -9
 ERROR_INVAL, ERROR_NOMEM, ERROR_BUSY = -10, -11, -12
 
-OUT_PCM, OUT_F32, VU, INPLACE, EQ = 0x1, 0x2, 0x4, 0x8, 0x10
+OUT_PCM, OUT_F32, VU, INPLACE, EQ, HOSTPCM = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 GEN_NULL, GEN_SINE, GEN_NOISE = 0, 1, 2
 NODE_WORDS = 34
 

@@ -148,6 +148,8 @@ struct cmhip_batch {
     size_t plane;                  // floats between f32 planes
 
     int16_t *d_in, *d_out;
+    int16_t *h_in, *h_out;         // CMHIP_HOSTPCM: the slots live in pinned host memory (d_* alias them)
+    bool in_flight;                // a launch may still be using the slots (CMHIP_HOSTPCM)
     float *d_f32;
     StreamParam *d_param;
     VuState *d_vu;                         // the window runs accumulate into (= d_vu2[cur])
@@ -251,9 +253,16 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     for (int i = 0; i < 2; i++)
         if (b->snap_event2[i])
             (void)hipEventDestroy(b->snap_event2[i]);
-    if (b->d_out && b->d_out != b->d_in)
-        (void)hipFree(b->d_out);
-    (void)hipFree(b->d_in);
+    if (b->d.flags & CMHIP_HOSTPCM) {
+        if (b->h_out && b->h_out != b->h_in)
+            (void)hipHostFree(b->h_out);
+        if (b->h_in)
+            (void)hipHostFree(b->h_in);
+    } else {
+        if (b->d_out && b->d_out != b->d_in)
+            (void)hipFree(b->d_out);
+        (void)hipFree(b->d_in);
+    }
     (void)hipFree(b->d_f32);
     (void)hipFree(b->d_param);
     for (int i = 0; i < 3; i++)
@@ -302,13 +311,30 @@ static int batch_init(cmhip_batch_t *b)
     b->plane = (d.max_frames + 63) / 64 * 64;
 
     const size_t pcm_bytes = S * b->stride * sizeof(int16_t);
-    HIP_TRY(hipMalloc((void **)&b->d_in, pcm_bytes));
-    HIP_TRY(hipMemsetAsync(b->d_in, 0, pcm_bytes, b->stream));
-    if ((d.flags & CMHIP_OUT_PCM) && !(d.flags & CMHIP_INPLACE)) {
-        HIP_TRY(hipMalloc((void **)&b->d_out, pcm_bytes));
-        HIP_TRY(hipMemsetAsync(b->d_out, 0, pcm_bytes, b->stream));
-    } else if (d.flags & CMHIP_OUT_PCM) {
-        b->d_out = b->d_in;
+    if (d.flags & CMHIP_HOSTPCM) {
+        // zero copy: the kernels read and write pinned, device-mapped host memory; an upload or
+        // download is a memcpy on the host (for the 1 KiB blocks of the per-stream stages the
+        // two DMA submissions cost more than the block itself)
+        HIP_TRY(hipHostMalloc((void **)&b->h_in, pcm_bytes, hipHostMallocMapped));
+        memset(b->h_in, 0, pcm_bytes);
+        HIP_TRY(hipHostGetDevicePointer((void **)&b->d_in, b->h_in, 0));
+        if ((d.flags & CMHIP_OUT_PCM) && !(d.flags & CMHIP_INPLACE)) {
+            HIP_TRY(hipHostMalloc((void **)&b->h_out, pcm_bytes, hipHostMallocMapped));
+            memset(b->h_out, 0, pcm_bytes);
+            HIP_TRY(hipHostGetDevicePointer((void **)&b->d_out, b->h_out, 0));
+        } else if (d.flags & CMHIP_OUT_PCM) {
+            b->h_out = b->h_in;
+            b->d_out = b->d_in;
+        }
+    } else {
+        HIP_TRY(hipMalloc((void **)&b->d_in, pcm_bytes));
+        HIP_TRY(hipMemsetAsync(b->d_in, 0, pcm_bytes, b->stream));
+        if ((d.flags & CMHIP_OUT_PCM) && !(d.flags & CMHIP_INPLACE)) {
+            HIP_TRY(hipMalloc((void **)&b->d_out, pcm_bytes));
+            HIP_TRY(hipMemsetAsync(b->d_out, 0, pcm_bytes, b->stream));
+        } else if (d.flags & CMHIP_OUT_PCM) {
+            b->d_out = b->d_in;
+        }
     }
     if (d.flags & CMHIP_OUT_F32) {
         const size_t fbytes = S * d.channels * b->plane * sizeof(float);
@@ -385,6 +411,8 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->stream = nullptr;
     b->own_stream = false;
     b->d_in = b->d_out = nullptr;
+    b->h_in = b->h_out = nullptr;
+    b->in_flight = false;
     b->d_f32 = nullptr;
     b->d_param = nullptr;
     b->d_vu = nullptr;
@@ -601,6 +629,16 @@ extern "C" void *cmhip_batch_dev_out(cmhip_batch_t *b) { return b ? b->d_out : n
 extern "C" void *cmhip_batch_dev_f32(cmhip_batch_t *b) { return b ? b->d_f32 : nullptr; }
 extern "C" void *cmhip_batch_hip_stream(cmhip_batch_t *b) { return b ? (void *)b->stream : nullptr; }
 
+// CMHIP_HOSTPCM: the host may touch the slots only while no launch is using them
+static int host_slots_quiet(cmhip_batch_t *b)
+{
+    if (b->in_flight) {
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        b->in_flight = false;
+    }
+    return COOLMIC_ERROR_NONE;
+}
+
 extern "C" int cmhip_batch_upload(cmhip_batch_t *b, unsigned int stream, const int16_t *pcm,
                                   size_t frames)
 {
@@ -614,6 +652,12 @@ extern "C" int cmhip_batch_upload(cmhip_batch_t *b, unsigned int stream, const i
     int16_t *dst = b->d_in + (size_t)stream * b->stride;
     if (bytes == 0)
         return COOLMIC_ERROR_NONE;
+    if (b->h_in) {
+        if (host_slots_quiet(b))
+            return COOLMIC_ERROR_GENERIC;
+        memcpy(b->h_in + (size_t)stream * b->stride, pcm, bytes);
+        return COOLMIC_ERROR_NONE;
+    }
     if (bytes <= STAGE_BYTES) {
         // small blocks (the 1 KiB pulls of the per-stream stages): bounce through pinned
         // memory so the caller may reuse its buffer as soon as we return
@@ -645,6 +689,12 @@ extern "C" int cmhip_batch_upload_all(cmhip_batch_t *b, const int16_t *host, siz
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     const size_t span = ((size_t)(b->d.streams - 1) * b->stride + frames * b->d.channels) * sizeof(int16_t);
+    if (b->h_in) {
+        if (host_slots_quiet(b))
+            return COOLMIC_ERROR_GENERIC;
+        memcpy(b->h_in, host, span);
+        return COOLMIC_ERROR_NONE;
+    }
     HIP_TRY(hipMemcpyAsync(b->d_in, host, span, hipMemcpyHostToDevice, b->stream));
     return COOLMIC_ERROR_NONE;
 }
@@ -660,6 +710,12 @@ extern "C" int cmhip_batch_download_all(cmhip_batch_t *b, int16_t *host, size_t 
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     const size_t span = ((size_t)(b->d.streams - 1) * b->stride + frames * b->d.channels) * sizeof(int16_t);
+    if (b->h_out) {
+        if (host_slots_quiet(b))
+            return COOLMIC_ERROR_GENERIC;
+        memcpy(host, b->h_out, span);
+        return COOLMIC_ERROR_NONE;
+    }
     HIP_TRY(hipMemcpyAsync(host, b->d_out, span, hipMemcpyDeviceToHost, b->stream));
     return COOLMIC_ERROR_NONE;
 }
@@ -692,6 +748,12 @@ extern "C" int cmhip_batch_download(cmhip_batch_t *b, unsigned int stream, int16
         return fail(COOLMIC_ERROR_INVAL, "download: stream or frames out of range");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
+    if (b->h_out) {
+        if (host_slots_quiet(b))
+            return COOLMIC_ERROR_GENERIC;
+        memcpy(pcm, b->h_out + (size_t)stream * b->stride, frames * b->d.channels * sizeof(int16_t));
+        return COOLMIC_ERROR_NONE;
+    }
     HIP_TRY(hipMemcpyAsync(pcm, b->d_out + (size_t)stream * b->stride,
                            frames * b->d.channels * sizeof(int16_t), hipMemcpyDeviceToHost,
                            b->stream));
@@ -708,6 +770,12 @@ extern "C" int cmhip_batch_download_input(cmhip_batch_t *b, unsigned int stream,
         return fail(COOLMIC_ERROR_INVAL, "download_input: stream or frames out of range");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
+    if (b->h_in) {
+        if (host_slots_quiet(b))
+            return COOLMIC_ERROR_GENERIC;
+        memcpy(pcm, b->h_in + (size_t)stream * b->stride, frames * b->d.channels * sizeof(int16_t));
+        return COOLMIC_ERROR_NONE;
+    }
     HIP_TRY(hipMemcpyAsync(pcm, b->d_in + (size_t)stream * b->stride,
                            frames * b->d.channels * sizeof(int16_t), hipMemcpyDeviceToHost,
                            b->stream));
@@ -757,6 +825,7 @@ extern "C" int cmhip_batch_generate(cmhip_batch_t *b, int mode, uint32_t seed, s
     if (coolmic_sine_period(48000, g.sine, &n) != COOLMIC_ERROR_NONE || n != 48)
         return fail(COOLMIC_ERROR_GENERIC, "generate: sine table unavailable");
     HIP_TRY(launch_generate(g, mode, b->stream));
+    b->in_flight = true;
     return COOLMIC_ERROR_NONE;
 }
 
@@ -842,6 +911,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.stride = b->stride;
         a.plane = b->plane;
         HIP_TRY(launch_eq(a, b->stream));
+        b->in_flight = true;
     } else {
         RunArgs a;
         memset(&a, 0, sizeof(a));
@@ -860,6 +930,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.identity_maps = b->all_identity ? 1u : 0u;
         a.parity = b->parity;
         HIP_TRY(launch_run(a, b->stream));
+        b->in_flight = true;
     }
     if (b->timing) {
         HIP_TRY(hipEventRecord(ev.b, b->stream));

@@ -118,7 +118,7 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
         d.channels = t->channels;
         d.rate = (unsigned int)t->rate;
         d.max_frames = TRANSFORM_SLICE_FRAMES;
-        d.flags = CMHIP_OUT_PCM | CMHIP_INPLACE | CMHIP_EQ;
+        d.flags = CMHIP_OUT_PCM | CMHIP_INPLACE | CMHIP_EQ | CMHIP_HOSTPCM;
         t->dev = cmhip_batch_new(&d);
         if (t->dev == NULL) {
             coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_NOSYS,

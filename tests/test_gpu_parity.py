@@ -538,6 +538,44 @@ def test_channel_maps_on_many_channels(gpu, oracle, C):
         b.close()
 
 
+@pytest.mark.parametrize("C", [1, 2, 6])
+def test_host_resident_slots(gpu, oracle, C):
+    """CMHIP_HOSTPCM: the PCM slots live in pinned host memory that the kernels read and write
+    directly (what the per-stream stages use for their 1 KiB blocks): same results, block after
+    block into one window, also in place and with the equaliser"""
+    cm = gpu
+    rng = np.random.default_rng(77 + C)
+    S, T = 5, 700
+    for extra in (0, cm.INPLACE, cm.EQ):
+        b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU | cm.HOSTPCM | extra)
+        gas = []
+        for s in range(S):
+            ga = None if s == 0 else (C, 1000, [int(v) for v in rng.integers(100, 3000, C)])
+            if ga:
+                assert b.set_gain(s, *ga) == 0
+            gas.append(ga)
+        wants = [[] for _ in range(S)]
+        for k in range(4):
+            lens = [int(v) for v in rng.integers(0, T + 1, S)]
+            xs = [_rand_pcm(rng, lens[s] * C, "full") for s in range(S)]
+            for s in range(S):
+                if lens[s]:
+                    b.upload(s, xs[s])
+            b.run(T, frames_per_stream=lens)
+            for s in range(S):
+                want = _oracle_block(oracle, xs[s], C, gas[s], None)
+                got = b.download(s, lens[s]) if lens[s] else np.zeros(0, np.int16)
+                assert np.array_equal(got, want), (C, extra, k, s)
+                wants[s].append(want)
+        for s in range(S):
+            rc_o, r_o = _oracle_vu(oracle, wants[s], C)
+            rc_g, r_g = b.vu_result(s)
+            assert rc_g == rc_o, (C, s)
+            if rc_o == 0:
+                assert r_g.as_dict() == of.vu_result_dict(r_o), (C, extra, s)
+        b.close()
+
+
 def test_batch_api_error_paths(gpu):
     """argument checking of the C ABI (include/coolmic_hip.h): errors are numbers, never faults"""
     import ctypes as C
