@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="override frames per launch")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
+    ap.add_argument("--strong", action="store_true",
+                    help="fixed total: the workload's streams are divided among the ranks (default: "
+                         "weak scaling, the workload's streams per GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip ceilings / VU-only line")
     args = ap.parse_args()
@@ -95,6 +98,10 @@ def main():
         T = args.frames
     if args.streams:
         S = args.streams
+    if args.strong:
+        if S % world:
+            raise SystemExit("--strong: %d streams do not divide among %d ranks" % (S, world))
+        S //= world
     eq = args.workload == "c3"
     node_vu = args.workload == "c5"
 
@@ -196,7 +203,7 @@ def main():
         "metric": "Msamples/s transform->vumeter", "value": round(value, 1), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "int16" if not eq else "f32",
+        "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "int16" if not eq else "f32",
         "arithmetic": "int16 PCM, exact int32 products / division, int64 VU accumulation, dB in f64 on the host"
         if not eq else "int16 in, exact integer gain, f32 biquads (fixed fmaf order), f32 out",
         "data": "synthetic (per-stream LCG noise generated on device, seed 12345 + stream id)",
