@@ -993,21 +993,76 @@ __device__ __forceinline__ int f32_to_i16(float y)
 // with state of its own -- and a workgroup takes G / C whole streams (MONO: the 16-byte
 // vector loads and packed stores of config 3; otherwise the T lanes gather their channel's
 // samples with 16-bit loads through the stream's channel map and the S lanes scatter them).
+//
+// Wave order.  Waves w, w+4 and w+8 of a workgroup share a SIMD, and a step lasts as long as
+// the most loaded SIMD needs (issue slots plus the time its waves are blocked on LDS writes):
+// per step an R wave costs ~1100 clk of that, a T-in wave (load, gain, section 0) ~600, a
+// T-ff wave (feed-forward of the later sections, 16 rows) ~850, the S wave ~600.  The order
+// below pairs them so that no SIMD carries much more than a quarter of the total.
+enum : u32 { EQ_R = 0x00, EQ_TIN = 0x10, EQ_TFF = 0x20, EQ_S = 0x30, EQ_TS = 0x40 };   // TS: T-ff and S in one wave
+
+// waves of a workgroup: float planes only (NSW == 1) -> the store work rides on the T-ff waves
+// (8 waves: two per SIMD, 256 VGPRs each); int16 / VU outputs (NSW == 4) -> S waves of their own
+template <int NSEC, int G, int NSW>
+constexpr u32 eq_waves()
+{
+    constexpr u32 nrw = (NSEC + 64 / G - 1) / (64 / G);
+    return NSW == 1 ? (NSEC > 1 ? nrw + G / 8 + 2 : nrw + G / 8 + 1) : nrw + G / 8 + (NSEC > 1 ? 2 : 0) + NSW;
+}
+
+template <int NRW, int NTF, int NSW>
+__device__ __forceinline__ u32 eq_role(u32 wave)
+{
+    if constexpr (NTF == 2 && NSW == 1) {
+        if constexpr (NRW == 2) {                // SIMDs: {R0 Tin0} {R1 Tin1} {TS0 Tin2} {TS1 Tin3}
+            constexpr unsigned char t[8] = {EQ_R | 0, EQ_R | 1, EQ_TS | 0, EQ_TS | 1, EQ_TIN | 0, EQ_TIN | 1,
+                                            EQ_TIN | 2, EQ_TIN | 3};
+            return t[wave];
+        } else {                                 // {R0 TS0} {Tin0 TS1} {Tin1 Tin3} {Tin2}
+            constexpr unsigned char t[7] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 1, EQ_TIN | 2, EQ_TS | 0, EQ_TS | 1,
+                                            EQ_TIN | 3};
+            return t[wave];
+        }
+    } else if constexpr (NTF == 2) {
+        if constexpr (NRW == 2) {                // {Tff1 Tin0 S0} {R0 Tin1 S1} {R1 Tin2 S2} {Tff0 Tin3 S3}
+            constexpr unsigned char t[12] = {EQ_TFF | 1, EQ_R | 0, EQ_R | 1, EQ_TFF | 0, EQ_TIN | 0, EQ_TIN | 1,
+                                             EQ_TIN | 2, EQ_TIN | 3, EQ_S | 0, EQ_S | 1, EQ_S | 2, EQ_S | 3};
+            return t[wave];
+        } else {
+            constexpr unsigned char t[11] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 2, EQ_TIN | 3, EQ_S | 0, EQ_TIN | 1,
+                                             EQ_TFF | 0, EQ_TFF | 1, EQ_S | 1, EQ_S | 2, EQ_S | 3};
+            return t[wave];
+        }
+    } else if constexpr (NSW == 1) {             // one section: no T-ff waves
+        constexpr unsigned char t[6] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 1, EQ_TIN | 2, EQ_S | 0, EQ_TIN | 3};
+        return t[wave];
+    } else {
+        constexpr unsigned char t[9] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 1, EQ_TIN | 2, EQ_S | 0, EQ_TIN | 3,
+                                        EQ_S | 1, EQ_S | 2, EQ_S | 3};
+        return t[wave];
+    }
+}
+
 template <int NSEC, int G, int NSW, bool MONO>
-__global__ __launch_bounds__((((NSEC + 64 / G - 1) / (64 / G)) + G / 8 + NSW) * 64)
+__global__ __launch_bounds__((eq_waves<NSEC, G, NSW>() * 64))
 void k_eq_pipe(EqArgs a)
 {
+    static_assert(G == 32, "the wave order below is laid out for 32 rows per workgroup");
     constexpr u32 EP_TB = 64;                     // frames per block
     constexpr u32 EP_ROW = EP_TB + 4;             // floats per LDS row
     constexpr u32 EP_TILE = G * EP_ROW;           // floats per buffer slot
     constexpr u32 SPW = 64 / G;                   // sections per R wave
     constexpr u32 NRW = (NSEC + SPW - 1) / SPW;   // R waves
-    constexpr u32 NTW = G / 8;                    // T waves: 8 rows x 8 chunks each
+    constexpr u32 NTF = NSEC > 1 ? 2 : 0;         // T-ff waves: G / 2 rows each, in PASSES of 8 rows
+    constexpr u32 PASSES = 2;
     constexpr u32 NBUF = 2 * NSEC;                // F_0, Y_0, F_1, Y_1, ...
     constexpr u32 SPR = EP_TB / 4;                // store lanes per row (4 frames each)
     constexpr u32 RPI = 64 / SPR;                 // rows per store instruction
     constexpr int DPP_SHR1 = 0x111, DPP_SHL7 = 0x107;
-    constexpr u32 HOP = CMHIP_EQ_RLAG ? 3 : 2;     // steps from F_k to F_k+1
+    // the register prefetch of the R waves needs 128 VGPRs for two rows: only where the workgroup
+    // has at most two waves per SIMD (256 VGPRs each); with S waves of their own it would spill
+    constexpr bool RLAG = CMHIP_EQ_RLAG && eq_waves<NSEC, G, NSW>() <= 8;
+    constexpr u32 HOP = RLAG ? 3 : 2;             // steps from F_k to F_k+1
     extern __shared__ float lds[];                // NBUF buffers x 2 slots x EP_TILE floats, then G counts
     u32 *nfr_lds = reinterpret_cast<u32 *>(lds + NBUF * 2 * EP_TILE);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -1021,13 +1076,17 @@ void k_eq_pipe(EqArgs a)
         return q < SPG ? s0 + q : 0xffffffffu;            // rows past the last whole stream idle
     };
 
-    const bool is_rec = wave < NRW;
-    const bool is_store = wave >= NRW + NTW;              // the S waves
-    const u32 sw = wave - NRW - NTW;                      // S wave index
-    const u32 tw = wave - NRW;                            // T wave index
+    const u32 role = eq_role<(int)NRW, (int)NTF, NSW>(wave);
+    const bool is_rec = (role & 0xf0u) == EQ_R;
+    const bool is_tin = (role & 0xf0u) == EQ_TIN;
+    const bool is_tff = (role & 0xf0u) == EQ_TFF || (role & 0xf0u) == EQ_TS;
+    const bool is_store = (role & 0xf0u) == EQ_S || (role & 0xf0u) == EQ_TS;
+    constexpr u32 NSWE = (NSW == 1 && NSEC > 1) ? 2 : NSW;        // waves that do the store work
+    const u32 sw = role & 15u;                            // S wave index
+    const u32 tw = role & 15u;                            // T-in / T-ff wave index
 
     // R lanes: section and stream row
-    const u32 sec = wave * SPW + lane / G;
+    const u32 sec = (role & 15u) * SPW + lane / G;
     const bool has_sec = is_rec && sec < (u32)NSEC;
     const u32 row = lane % G;
     u32 my_ch;
@@ -1061,36 +1120,56 @@ void k_eq_pipe(EqArgs a)
     u32 l_ch;
     const u32 l_stream = row_stream(l_r, l_ch);
     const u32 l_s = min(l_stream, a.streams - 1);
-    const bool l_live = !is_rec && !is_store && l_stream < a.streams;
+    const bool l_live = is_tin && l_stream < a.streams;
     const u32 l_sidx = l_s * C + l_ch;
     u32 l_magic = 0, l_shift = 0, l_g2 = 0, l_n = 0, l_m = 0;
-    float fc[NSEC][3];                                    // b0 b1 b2 of every section of this row
-    float sx1[NSEC], sx2[NSEC];                           // x[t-1], x[t-2] before the next block
+    // feed-forward registers: b0 b1 b2 and x[t-1], x[t-2] before the next block.  A T-in lane
+    // uses [0][0] for section 0 of its row; a T-ff lane [p][k] for section k of the row of pass p.
+    float fc[PASSES][NSEC][3];
+    float sx1[PASSES][NSEC], sx2[PASSES][NSEC];
 #pragma unroll
-    for (int k = 0; k < NSEC; k++) {
-        fc[k][0] = fc[k][1] = fc[k][2] = 0.f;
-        sx1[k] = sx2[k] = 0.f;
-    }
-    if (!is_rec && !is_store) {
+    for (u32 p = 0; p < PASSES; p++)
+#pragma unroll
+        for (int k = 0; k < NSEC; k++) {
+            fc[p][k][0] = fc[p][k][1] = fc[p][k][2] = 0.f;
+            sx1[p][k] = sx2[p][k] = 0.f;
+        }
+    if (is_tin) {
         l_magic = a.param[l_s].magic;
         l_shift = a.param[l_s].shift;
         l_g2 = a.param[l_s].gain2[l_ch];
         l_m = MONO ? 0u : a.param[l_s].chmap[l_ch];       // the input channel this row reads
         l_n = nfr_lds[l_r];
         if (l_live) {
+            // section 0 sees integer-valued samples (the 2^-15 of "x / 32768.f" is not applied
+            // by the conversion): it is folded into the coefficients instead, which is
+            // bit-identical because power-of-two scaling commutes with every rounding of the
+            // chain.  Its history is kept in the same unscaled form inside the kernel and
+            // converted at the EqState boundary.
+            const float *c = a.eq[l_s].coef[0];
+            const float *st = a.state[l_sidx].s[0];
+            fc[0][0][0] = c[0] * (1.0f / 32768.0f);
+            fc[0][0][1] = c[1] * (1.0f / 32768.0f);
+            fc[0][0][2] = c[2] * (1.0f / 32768.0f);
+            sx1[0][0] = st[0] * 32768.0f;
+            sx2[0][0] = st[1] * 32768.0f;
+        }
+    }
+    u32 f_r[PASSES];                                      // T-ff: row of pass p
 #pragma unroll
-            for (int k = 0; k < NSEC; k++) {
-                // section 0 sees integer-valued samples (the 2^-15 of "x / 32768.f" is not
-                // applied by the conversion): it is folded into the coefficients instead, which
-                // is bit-identical because power-of-two scaling commutes with every rounding
-                // of the chain.  Its history is kept in the same unscaled form inside the
-                // kernel and converted at the EqState boundary.
-                const float sc = k == 0 ? (1.0f / 32768.0f) : 1.0f;
-                const float si = k == 0 ? 32768.0f : 1.0f;
-                const float *c = a.eq[l_s].coef[k];
-                const float *st = a.state[l_sidx].s[k];
-                fc[k][0] = c[0] * sc; fc[k][1] = c[1] * sc; fc[k][2] = c[2] * sc;
-                sx1[k] = st[0] * si; sx2[k] = st[1] * si;
+    for (u32 p = 0; p < PASSES; p++) {
+        f_r[p] = (G / 2u) * tw + 8u * p + lane / 8u;
+        if (is_tff) {
+            u32 fch;
+            const u32 fs = row_stream(f_r[p], fch);
+            if (fs < a.streams) {
+#pragma unroll
+                for (int k = 1; k < NSEC; k++) {
+                    const float *c = a.eq[fs].coef[k];
+                    const float *st = a.state[fs * C + fch].s[k];
+                    fc[p][k][0] = c[0]; fc[p][k][1] = c[1]; fc[p][k][2] = c[2];
+                    sx1[p][k] = st[0]; sx2[p][k] = st[1];
+                }
             }
         }
     }
@@ -1120,21 +1199,21 @@ void k_eq_pipe(EqArgs a)
         }
     };
     u32x4 wa = {0, 0, 0, 0}, wb = {0, 0, 0, 0};           // blocks of even / odd steps
-    if (!is_rec && !is_store) {
+    if (is_tin) {
         wa = fetch(0);
         wb = fetch(1);
     }
 
     // feed-forward half of section k on the 8 samples of this lane; the two samples before
     // them come from the lane to the left, or (first chunk) from the end of the last block
-    auto feed_forward = [&](const int k, const float (&x)[8], float (&f)[8]) {
+    auto feed_forward = [&](const u32 p, const int k, const float (&x)[8], float (&f)[8]) {
         const float p1 = dpp_f32<DPP_SHR1>(x[7]), p2 = dpp_f32<DPP_SHR1>(x[6]);
-        const float q1 = dpp_f32<DPP_SHL7>(sx1[k]), q2 = dpp_f32<DPP_SHL7>(sx2[k]);
+        const float q1 = dpp_f32<DPP_SHL7>(sx1[p][k]), q2 = dpp_f32<DPP_SHL7>(sx2[p][k]);
         const float xm1 = l_c == 0 ? q1 : p1;
         const float xm2 = l_c == 0 ? q2 : p2;
-        sx1[k] = x[7];
-        sx2[k] = x[6];
-        const float c0 = fc[k][0], c1 = fc[k][1], c2 = fc[k][2];
+        sx1[p][k] = x[7];
+        sx2[p][k] = x[6];
+        const float c0 = fc[p][k][0], c1 = fc[p][k][1], c2 = fc[p][k][2];
         f[0] = __builtin_fmaf(c2, xm2, __builtin_fmaf(c1, xm1, c0 * x[0]));
         f[1] = __builtin_fmaf(c2, xm1, __builtin_fmaf(c1, x[0], c0 * x[1]));
 #pragma unroll
@@ -1154,7 +1233,7 @@ void k_eq_pipe(EqArgs a)
         if (!(CMHIP_EQ_ABL & 32)) {
             const u32 first = HOP * sec + HOP - 1u;       // step in which block 0 is worked on
             const u32 b = step - first;
-            if (CMHIP_EQ_RLAG) {                          // next block's row: into registers now
+            if (RLAG) {                                   // next block's row: into registers now
                 const u32 bp = b + 1u;
                 if (has_sec && step + 1u >= first && bp < nblocks) {
                     const float4 *in = reinterpret_cast<const float4 *>(
@@ -1167,7 +1246,7 @@ void k_eq_pipe(EqArgs a)
             if (has_sec && step >= first && b < nblocks) {
                 float4 *out = reinterpret_cast<float4 *>(
                     lds + ((2u * sec + 1u) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW);
-                if (!CMHIP_EQ_RLAG) {
+                if (!RLAG) {
                     const float4 *in = reinterpret_cast<const float4 *>(
                         lds + ((2u * sec) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW);
 #pragma unroll
@@ -1216,24 +1295,11 @@ void k_eq_pipe(EqArgs a)
     };
     float keep1 = 0.f, keep2 = 0.f;                       // section 0's new x1 / x2, if seen
     bool has1 = false, has2 = false;
-    auto t_step = [&](u32x4 &wcur, const u32 step) {
+    auto tin_step = [&](u32x4 &wcur, const u32 step) {
         if (!(CMHIP_EQ_ABL & 128)) {
 #ifdef CMHIP_EQ_STAMPS
             const u64 st_tt = __builtin_readcyclecounter();
 #endif
-            // rows of the later sections first: their LDS latency passes behind the conversion
-            float4 yin[NSEC][2];
-#pragma unroll
-            for (int k = 1; k < NSEC; k++) {
-                const u32 b = step - HOP * (u32)k;
-                yin[k][0] = yin[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!(CMHIP_EQ_ABL & 16) && step >= HOP * (u32)k && b < nblocks) {
-                    const float4 *src = reinterpret_cast<const float4 *>(
-                        lds + ((2u * k - 1u) * 2u + (b & 1u)) * EP_TILE + l_r * EP_ROW + l_t8);
-                    yin[k][0] = src[0];
-                    yin[k][1] = src[1];
-                }
-            }
             // --- input block `step`: PCM -> gain -> float -> feed-forward of section 0 -> F_0
             // (also in the drain steps at the end, where it works on zeros: keeping the load
             // unconditional is what lets the wait above be counted)
@@ -1298,7 +1364,7 @@ void k_eq_pipe(EqArgs a)
                             has2 = true;
                         }
                     } else if (l_c == 7u) {
-                        keep2 = sx1[0];                               // the sample before this block
+                        keep2 = sx1[0][0];                            // the sample before this block
                         has2 = true;
                     }
                 }
@@ -1306,7 +1372,7 @@ void k_eq_pipe(EqArgs a)
                 asm volatile("" : "+v"(x[7]));
                 st_p[1] += __builtin_readcyclecounter() - st_tt;          // converted
 #endif
-                feed_forward(0, x, f);
+                feed_forward(0, 0, x, f);
                 float4 *dst = reinterpret_cast<float4 *>(lds + (b & 1u) * EP_TILE + l_r * EP_ROW + l_t8);
                 dst[0] = make_float4(f[0], f[1], f[2], f[3]);
                 dst[1] = make_float4(f[4], f[5], f[6], f[7]);
@@ -1315,32 +1381,60 @@ void k_eq_pipe(EqArgs a)
                 st_p[2] += __builtin_readcyclecounter() - st_tt;          // F_0 handed to the LDS queue
 #endif
             }
-            // --- feed-forward of the later sections: Y_k-1 -> F_k
+        }
+    };
+    // T-ff waves: feed-forward of the later sections, Y_k-1 -> F_k, for G / 2 rows in PASSES of
+    // eight (each with the history registers of its own rows)
+    auto tff_step = [&](const u32 step) {
+        if (!(CMHIP_EQ_ABL & (128 | 16))) {
+            // reads first, then arithmetic: one LDS latency per step where the registers allow
+            // it (two waves per SIMD), one per pass otherwise
+            constexpr u32 PG = RLAG ? PASSES : 1;         // passes whose rows are loaded together
 #pragma unroll
-            for (int k = 1; k < NSEC; k++) {
-                const u32 b = step - HOP * (u32)k;
-                if (!(CMHIP_EQ_ABL & 16) && step >= HOP * (u32)k && b < nblocks) {
-                    const float4 v0 = yin[k][0], v1 = yin[k][1];
-                    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                    float f[8];
-                    feed_forward(k, x, f);
-                    float4 *dst = reinterpret_cast<float4 *>(
-                        lds + ((2u * k) * 2u + (b & 1u)) * EP_TILE + l_r * EP_ROW + l_t8);
-                    dst[0] = make_float4(f[0], f[1], f[2], f[3]);
-                    dst[1] = make_float4(f[4], f[5], f[6], f[7]);
+            for (u32 p0 = 0; p0 < PASSES; p0 += PG) {
+                float4 yin[PG][NSEC][2];
+#pragma unroll
+                for (int k = 1; k < NSEC; k++) {
+                    const u32 b = step - HOP * (u32)k;
+                    if (step >= HOP * (u32)k && b < nblocks) {
+#pragma unroll
+                        for (u32 p = 0; p < PG; p++) {
+                            const float4 *src = reinterpret_cast<const float4 *>(
+                                lds + ((2u * k - 1u) * 2u + (b & 1u)) * EP_TILE + f_r[p0 + p] * EP_ROW + l_t8);
+                            yin[p][k][0] = src[0];
+                            yin[p][k][1] = src[1];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 1; k < NSEC; k++) {
+                    const u32 b = step - HOP * (u32)k;
+                    if (step >= HOP * (u32)k && b < nblocks) {
+#pragma unroll
+                        for (u32 p = 0; p < PG; p++) {
+                            const float4 v0 = yin[p][k][0], v1 = yin[p][k][1];
+                            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                            float f[8];
+                            feed_forward(p0 + p, k, x, f);
+                            float4 *dst = reinterpret_cast<float4 *>(
+                                lds + ((2u * k) * 2u + (b & 1u)) * EP_TILE + f_r[p0 + p] * EP_ROW + l_t8);
+                            dst[0] = make_float4(f[0], f[1], f[2], f[3]);
+                            dst[1] = make_float4(f[4], f[5], f[6], f[7]);
+                        }
+                    }
                 }
             }
         }
     };
     // S wave: per row slot i (rows RPI*i + lane/16) the VU window of the int16 result
-    static_assert((G / RPI) % NSW == 0, "row slots must divide among the S waves");
-    constexpr u32 NSL = G / RPI / NSW;                    // row slots of one S wave
+    static_assert((G / RPI) % NSWE == 0, "row slots must divide among the S waves");
+    constexpr u32 NSL = G / RPI / NSWE;                   // row slots of one S wave
     u64 vpw[NSL], vky[NSL], vbase[NSL];
     u32 v_stream[NSL], v_ch[NSL];                         // stream (or none) and channel of the slot's row
 #pragma unroll
     for (u32 i = 0; i < NSL; i++) {
         vpw[i] = vky[i] = vbase[i] = 0;
-        const u32 r = RPI * (i * NSW + sw) + lane / SPR;
+        const u32 r = RPI * (i * NSWE + sw) + lane / SPR;
         v_stream[i] = row_stream(r, v_ch[i]);
         if (v_stream[i] >= a.streams)
             v_stream[i] = 0xffffffffu;
@@ -1355,13 +1449,20 @@ void k_eq_pipe(EqArgs a)
             const u32 b = step - HOP * NSEC;
             if (step >= HOP * NSEC && b < nblocks) {
                 const float *Y = lds + ((2u * NSEC - 1u) * 2u + (b & 1u)) * EP_TILE;
+                const u32 t4 = (lane % SPR) * 4u;
+                const u32 f0 = b * EP_TB + t4;
+                float4 vin[NSL];                              // every LDS read of the step up front:
+                u32 nin[NSL];                                 // one latency, not one per row slot
 #pragma unroll
                 for (u32 i = 0; i < NSL; i++) {
-                    const u32 r = RPI * (i * NSW + sw) + lane / SPR;
-                    const u32 t4 = (lane % SPR) * 4u;
-                    const u32 f0 = b * EP_TB + t4;
-                    const u32 n = nfr_lds[r];
-                    const float4 v = *reinterpret_cast<const float4 *>(Y + r * EP_ROW + t4);
+                    const u32 r = RPI * (i * NSWE + sw) + lane / SPR;
+                    nin[i] = nfr_lds[r];
+                    vin[i] = *reinterpret_cast<const float4 *>(Y + r * EP_ROW + t4);
+                }
+#pragma unroll
+                for (u32 i = 0; i < NSL; i++) {
+                    const u32 n = nin[i];
+                    const float4 v = vin[i];
                     const float e[4] = {v.x, v.y, v.z, v.w};
                     const u32 vs_ = v_stream[i], vc_ = v_ch[i];
                     if (vs_ == 0xffffffffu)
@@ -1458,8 +1559,13 @@ void k_eq_pipe(EqArgs a)
             EQ_STEP(rec_step(rb, ra, step + 1));
         }
     } else if (is_store) {
-        for (u32 step = 0; step < nst2; step++)
-            EQ_STEP(s_step(step));
+        if (is_tff) {                                     // float planes only: T-ff and S in one wave
+            for (u32 step = 0; step < nst2; step++)
+                EQ_STEP((tff_step(step), s_step(step)));
+        } else {
+            for (u32 step = 0; step < nst2; step++)
+                EQ_STEP(s_step(step));
+        }
         if (a.vu) {
             // the 16 lanes of a row hold parts of its window; lane 0 of them is the row's only writer
 #pragma unroll
@@ -1471,7 +1577,7 @@ void k_eq_pipe(EqArgs a)
                     const u64 ok = (u64)__shfl_xor((long long)ky, o, 64);
                     ky = ok > ky ? ok : ky;
                 }
-                const u32 r = RPI * (i * NSW + sw) + lane / SPR;
+                const u32 r = RPI * (i * NSWE + sw) + lane / SPR;
                 if (lane % SPR == 0 && v_stream[i] != 0xffffffffu) {
                     VuState *vs = a.vu + v_stream[i];
                     if (v_ch[i] == 0)
@@ -1482,10 +1588,13 @@ void k_eq_pipe(EqArgs a)
                 }
             }
         }
+    } else if (is_tff) {
+        for (u32 step = 0; step < nst2; step++)
+            EQ_STEP(tff_step(step));
     } else {
         for (u32 step = 0; step < nst2; step += 2) {
-            EQ_STEP(t_step(wa, step));
-            EQ_STEP(t_step(wb, step + 1));
+            EQ_STEP(tin_step(wa, step));
+            EQ_STEP(tin_step(wb, step + 1));
         }
         if (has1)
             a.state[l_sidx].s[0][0] = keep1 * (1.0f / 32768.0f);
@@ -1499,10 +1608,11 @@ void k_eq_pipe(EqArgs a)
         a.dbg[2 * wave + 1] = __builtin_readcyclecounter() - st_begin;
         a.dbg[41 + wave] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_ID
         a.dbg[40] = nsteps;
-        if (wave >= NRW && wave < NRW + 2) {          // two T waves: phases inside a step
+        if (is_tin && tw < 2) {                       // two T-in waves: phases inside a step
             for (int i = 0; i < 3; i++)
-                a.dbg[50 + 3 * (wave - NRW) + i] = st_p[i];
+                a.dbg[50 + 3 * tw + i] = st_p[i];
         }
+        a.dbg[20 + wave] = role;
     }
 #endif
 
@@ -1544,10 +1654,9 @@ static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
             return e;
         configured = true;
     }
-    constexpr int SPW = 64 / G, NRW = (NSEC + SPW - 1) / SPW;
     const u32 spg = MONO ? G : G / a.channels;            // whole streams per workgroup
     hipLaunchKernelGGL((k_eq_pipe<NSEC, G, NSW, MONO>), dim3((a.streams + spg - 1) / spg),
-                       dim3((NRW + G / 8 + NSW) * 64), lds_bytes, st, a);
+                       dim3(eq_waves<NSEC, G, NSW>() * 64), lds_bytes, st, a);
     return hipGetLastError();
 }
 

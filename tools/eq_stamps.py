@@ -23,9 +23,10 @@ assert cm.lib.cmhip_debug_read(b.h, out) == 0
 nsteps = out[40]
 print("G =", os.environ.get("CMHIP_EQ_G", "default"), "steps", nsteps)
 for w in range(16):
-    if out[2 * w + 1]:
+    if out[2 * w + 1] > nsteps:
         hw = out[41 + w]
-        print(f"wave {w:2d}: busy {out[2*w]/nsteps:8.1f} clk/step   total {out[2*w+1]/nsteps:8.1f} clk/step   "
+        role = {0: "R", 1: "Tin", 2: "Tff", 3: "S", 4: "Tff+S"}[(out[20 + w] >> 4) & 7] + str(out[20 + w] & 15)
+        print(f"wave {w:2d} {role:6s}: busy {out[2*w]/nsteps:8.1f} clk/step   total {out[2*w+1]/nsteps:8.1f} clk/step   "
               f"SIMD {(hw >> 4) & 3}  CU {(hw >> 8) & 15}  wave slot {hw & 15}")
 for i in range(2):
     p = [out[50 + 3 * i + j] / nsteps for j in range(3)]
