@@ -1015,8 +1015,19 @@ __device__ __forceinline__ u32 eq_role(u32 wave)
 {
     if constexpr (NTF == 2 && NSW == 1) {
         if constexpr (NRW == 2) {                // SIMDs: {R0 Tin0} {R1 Tin1} {TS0 Tin2} {TS1 Tin3}
+#if defined(CMHIP_EQ_ORDER) && CMHIP_EQ_ORDER == 1   // {R0 TS0} {R1 TS1} {Tin0 Tin2} {Tin1 Tin3}
+            constexpr unsigned char t[8] = {EQ_R | 0, EQ_R | 1, EQ_TIN | 0, EQ_TIN | 1, EQ_TS | 0, EQ_TS | 1,
+                                            EQ_TIN | 2, EQ_TIN | 3};
+#elif defined(CMHIP_EQ_ORDER) && CMHIP_EQ_ORDER == 2 // {R0 Tin0} {R1 TS0} {Tin1 TS1} {Tin2 Tin3}
+            constexpr unsigned char t[8] = {EQ_R | 0, EQ_R | 1, EQ_TIN | 1, EQ_TIN | 2, EQ_TIN | 0, EQ_TS | 0,
+                                            EQ_TS | 1, EQ_TIN | 3};
+#elif defined(CMHIP_EQ_ORDER) && CMHIP_EQ_ORDER == 3 // {R0 R1} {TS0 TS1} {Tin0 Tin1} {Tin2 Tin3}
+            constexpr unsigned char t[8] = {EQ_R | 0, EQ_TS | 0, EQ_TIN | 0, EQ_TIN | 2, EQ_R | 1, EQ_TS | 1,
+                                            EQ_TIN | 1, EQ_TIN | 3};
+#else
             constexpr unsigned char t[8] = {EQ_R | 0, EQ_R | 1, EQ_TS | 0, EQ_TS | 1, EQ_TIN | 0, EQ_TIN | 1,
                                             EQ_TIN | 2, EQ_TIN | 3};
+#endif
             return t[wave];
         } else {                                 // {R0 TS0} {Tin0 TS1} {Tin1 Tin3} {Tin2}
             constexpr unsigned char t[7] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 1, EQ_TIN | 2, EQ_TS | 0, EQ_TS | 1,
