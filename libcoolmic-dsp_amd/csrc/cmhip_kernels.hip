@@ -985,6 +985,9 @@ __device__ __forceinline__ int f32_to_i16(float y)
 #ifndef CMHIP_EQ_RLAG
 #define CMHIP_EQ_RLAG 1           // R waves load the next row into registers a step ahead (0: same step)
 #endif
+#ifndef CMHIP_EQ_RSLOTS
+#define CMHIP_EQ_RSLOTS 1         // row slots (of 8) whose stores each R wave takes when the output is float planes only
+#endif
 #ifndef CMHIP_EQ_ABL
 #define CMHIP_EQ_ABL 0            // `make abl`: timing-only builds with one part of the pipeline cut out
 #endif
@@ -1091,9 +1094,22 @@ void k_eq_pipe(EqArgs a)
     const bool is_rec = (role & 0xf0u) == EQ_R;
     const bool is_tin = (role & 0xf0u) == EQ_TIN;
     const bool is_tff = (role & 0xf0u) == EQ_TFF || (role & 0xf0u) == EQ_TS;
-    const bool is_store = (role & 0xf0u) == EQ_S || (role & 0xf0u) == EQ_TS;
-    constexpr u32 NSWE = (NSW == 1 && NSEC > 1) ? 2 : NSW;        // waves that do the store work
-    const u32 sw = role & 15u;                            // S wave index
+    // store work: the G / 4 row slots (four rows each) of Y_last are dealt out by role.  Float planes
+    // only, three or four sections: CMHIP_EQ_RSLOTS slots to each R wave, the rest to the T-ff waves
+    // (evens the SIMDs out); two sections: half to each T-ff wave; otherwise the S waves share them.
+    constexpr bool S_ON_R = NSW == 1 && NRW == 2 && NTF == 2;
+    constexpr u32 NSLOT = G / 4;
+    constexpr u32 RSL = CMHIP_EQ_RSLOTS, TSL = (NSLOT - 2 * RSL) / 2;    // slots of an R / a T-ff wave (S_ON_R)
+    constexpr u32 NSL = S_ON_R ? (RSL > TSL ? RSL : TSL) : (NSW == 1 && NTF == 2) ? NSLOT / 2 : NSLOT / NSW;
+    u32 s_first = 0, s_cnt = 0;                           // (NSL: most slots of a wave)
+    if (S_ON_R) {
+        if ((role & 0xf0u) == EQ_R) { s_first = RSL * (role & 15u); s_cnt = RSL; }
+        if ((role & 0xf0u) == EQ_TS) { s_first = 2u * RSL + TSL * (role & 15u); s_cnt = TSL; }
+    } else if ((role & 0xf0u) == EQ_S || (role & 0xf0u) == EQ_TS) {
+        s_first = NSL * (role & 15u);
+        s_cnt = NSL;
+    }
+    const bool is_store = s_cnt != 0;
     const u32 tw = role & 15u;                            // T-in / T-ff wave index
 
     // R lanes: section and stream row
@@ -1438,16 +1454,15 @@ void k_eq_pipe(EqArgs a)
         }
     };
     // S wave: per row slot i (rows RPI*i + lane/16) the VU window of the int16 result
-    static_assert((G / RPI) % NSWE == 0, "row slots must divide among the S waves");
-    constexpr u32 NSL = G / RPI / NSWE;                   // row slots of one S wave
+    static_assert(RPI == 4, "a row slot is four rows");
     u64 vpw[NSL], vky[NSL], vbase[NSL];
     u32 v_stream[NSL], v_ch[NSL];                         // stream (or none) and channel of the slot's row
 #pragma unroll
     for (u32 i = 0; i < NSL; i++) {
         vpw[i] = vky[i] = vbase[i] = 0;
-        const u32 r = RPI * (i * NSWE + sw) + lane / SPR;
+        const u32 r = RPI * (s_first + i) + lane / SPR;
         v_stream[i] = row_stream(r, v_ch[i]);
-        if (v_stream[i] >= a.streams)
+        if (v_stream[i] >= a.streams || i >= s_cnt)
             v_stream[i] = 0xffffffffu;
         if (is_store && a.vu && v_stream[i] != 0xffffffffu)
             vbase[i] = a.vu[v_stream[i]].samples[a.parity];
@@ -1466,7 +1481,7 @@ void k_eq_pipe(EqArgs a)
                 u32 nin[NSL];                                 // one latency, not one per row slot
 #pragma unroll
                 for (u32 i = 0; i < NSL; i++) {
-                    const u32 r = RPI * (i * NSWE + sw) + lane / SPR;
+                    const u32 r = min(RPI * (s_first + i) + lane / SPR, (u32)G - 1u);   // (slots past s_cnt are skipped below)
                     nin[i] = nfr_lds[r];
                     vin[i] = *reinterpret_cast<const float4 *>(Y + r * EP_ROW + t4);
                 }
@@ -1565,9 +1580,16 @@ void k_eq_pipe(EqArgs a)
 #pragma unroll
         for (u32 t = 0; t < EP_TB / 4; t++)
             ra[t] = rb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (u32 step = 0; step < nst2; step += 2) {
-            EQ_STEP(rec_step(ra, rb, step));
-            EQ_STEP(rec_step(rb, ra, step + 1));
+        if constexpr (S_ON_R) {                          // the recurrence first, then this wave's share of the stores
+            for (u32 step = 0; step < nst2; step += 2) {
+                EQ_STEP((rec_step(ra, rb, step), s_step(step)));
+                EQ_STEP((rec_step(rb, ra, step + 1), s_step(step + 1)));
+            }
+        } else {
+            for (u32 step = 0; step < nst2; step += 2) {
+                EQ_STEP(rec_step(ra, rb, step));
+                EQ_STEP(rec_step(rb, ra, step + 1));
+            }
         }
     } else if (is_store) {
         if (is_tff) {                                     // float planes only: T-ff and S in one wave
@@ -1588,7 +1610,7 @@ void k_eq_pipe(EqArgs a)
                     const u64 ok = (u64)__shfl_xor((long long)ky, o, 64);
                     ky = ok > ky ? ok : ky;
                 }
-                const u32 r = RPI * (i * NSWE + sw) + lane / SPR;
+                const u32 r = RPI * (s_first + i) + lane / SPR;
                 if (lane % SPR == 0 && v_stream[i] != 0xffffffffu) {
                     VuState *vs = a.vu + v_stream[i];
                     if (v_ch[i] == 0)
