@@ -1582,8 +1582,13 @@ void k_eq_pipe(EqArgs a)
             ra[t] = rb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (S_ON_R) {                          // the recurrence first, then this wave's share of the stores
             for (u32 step = 0; step < nst2; step += 2) {
+#if defined(CMHIP_EQ_V) && CMHIP_EQ_V == 1
+                EQ_STEP((s_step(step), rec_step(ra, rb, step)));
+                EQ_STEP((s_step(step + 1), rec_step(rb, ra, step + 1)));
+#else
                 EQ_STEP((rec_step(ra, rb, step), s_step(step)));
                 EQ_STEP((rec_step(rb, ra, step + 1), s_step(step + 1)));
+#endif
             }
         } else {
             for (u32 step = 0; step < nst2; step += 2) {
