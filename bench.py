@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="fixed total: the workload's streams are divided among the ranks (default: "
                          "weak scaling, the workload's streams per GPU)")
+    ap.add_argument("--node-batch", type=int, default=8,
+                    help="config 5: blocks whose node-global VU records travel in one all-gather")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip ceilings / VU-only line")
     args = ap.parse_args()
@@ -84,8 +86,10 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_node = os.environ.get("COOLMIC_BENCH_FORCE_NODE") == "1"       # single-rank test of the reduce path
+    if world > 1 or force_node:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29599")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -126,8 +130,35 @@ def main():
     has_vu = bool(flags & cm.VU)
     results = (cm.VuResult * S)()
     rcs = (C.c_int * S)()
-    node_words = torch.zeros(cm.NODE_WORDS, dtype=torch.int64, device="cuda") if node_vu else None
-    node_host = torch.zeros(cm.NODE_WORDS, dtype=torch.int64) if node_vu and rehearsal else None
+    # node-global VU (config 5): every block leaves one 34-word record per rank; the records of
+    # --node-batch blocks travel in ONE all-gather (the exchange is latency bound) and are combined
+    # on the device.  Two sets of record buffers alternate so that a set's exchange runs beside the
+    # next blocks' kernels; the batch's stream and torch's stream order themselves with events,
+    # the host never waits inside the loop.
+    node_on = node_vu and (world > 1 or force_node)
+    NB = max(1, args.node_batch)
+    node_sets = [torch.zeros(NB, cm.NODE_WORDS, dtype=torch.int64, device="cuda") for _ in range(2)] if node_vu else None
+    node_scratch = torch.empty(world, NB, cm.NODE_WORDS, dtype=torch.int64,
+                               device="cpu" if rehearsal else "cuda") if node_on else None
+    node_host = torch.zeros(NB, cm.NODE_WORDS, dtype=torch.int64) if node_on and rehearsal else None
+    ext_stream = torch.cuda.ExternalStream(b.hip_stream()) if node_on and not rehearsal else None
+    ev_ready = [torch.cuda.Event() for _ in range(2)] if ext_stream is not None else None
+    ev_done = [torch.cuda.Event() for _ in range(2)] if ext_stream is not None else None
+    node_step = [0]
+    node_result = [None]                   # combined records of the last exchanged set
+
+    def node_exchange(k):
+        words = node_sets[k]
+        if ext_stream is None:             # rehearsal (gloo): through a host copy
+            b.sync()
+            node_host.copy_(words)
+            node_result[0] = shard.gather_node_records(dist, node_host, node_scratch)
+        else:
+            ev_ready[k].record(ext_stream)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev_ready[k])                # RCCL runs after the records are written
+            node_result[0] = shard.gather_node_records(dist, words, node_scratch)
+            ev_done[k].record(cur)
 
     def barrier():
         torch.cuda.synchronize()
@@ -141,14 +172,15 @@ def main():
         pending = False
         for _ in range(n):
             b.run(T)
-            if node_vu and world > 1:
-                b.node_partial(node_words.data_ptr(), first_global=rank, global_step=world)
-                b.sync()      # the record is produced on the batch's stream, RCCL uses torch's
-                if rehearsal:                 # gloo: combine on the host copy
-                    node_host.copy_(node_words)
-                    shard.combine_node_records(dist, node_host)
-                else:
-                    shard.combine_node_records(dist, node_words)
+            if node_on:
+                i = node_step[0]
+                node_step[0] += 1
+                k, slot = (i // NB) & 1, i % NB
+                if slot == 0 and ext_stream is not None:
+                    ext_stream.wait_event(ev_done[k])      # the exchange that last used this set
+                b.node_partial(node_sets[k][slot].data_ptr(), first_global=rank, global_step=world)
+                if slot == NB - 1:
+                    node_exchange(k)
             if has_vu:
                 b.vu_snapshot()                      # async D2H of all windows + reset
                 if pending:
@@ -156,7 +188,12 @@ def main():
                 pending = True
         if pending:
             b.vu_collect(results, rcs)
+        if node_on and node_step[0] % NB:              # records of a partly filled set
+            node_exchange((node_step[0] // NB) & 1)
+            node_step[0] += NB - node_step[0] % NB
         b.sync()
+        if node_on and ext_stream is not None:
+            torch.cuda.current_stream().synchronize()
 
     run_steps(args.warmup)
     b.timing(True)
@@ -209,7 +246,8 @@ def main():
         "data": "synthetic (per-stream LCG noise generated on device, seed 12345 + stream id)",
         "config": {"workload": "%s: %s" % (args.workload, desc), "streams_per_gpu": S,
                    "channels": Cn, "frames_per_launch": T, "sharding": "stream s -> rank s %% %d" % world,
-                   "collective": "RCCL all-reduce (int64 SUM + MAX) per step" if node_vu else "none"},
+                   "collective": ("RCCL all-gather of %d blocks' node records (34 x int64 each), combined on the "
+                                  "device" % NB) if node_vu else "none"},
         "roofline": roofline,
     }
 
@@ -301,7 +339,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.workload, Cn)
 
-    if world > 1:
+    if world > 1 or force_node:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

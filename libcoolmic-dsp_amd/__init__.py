@@ -308,6 +308,10 @@ class Batch:
             assert a.size == self.streams
             _check("run", lib.cmhip_batch_run(self.h, frames, a.ctypes.data))
 
+    def hip_stream(self):
+        """the hipStream_t (as an integer) this batch launches on"""
+        return lib.cmhip_batch_hip_stream(self.h) or 0
+
     def sync(self):
         _check("sync", lib.cmhip_batch_sync(self.h))
 

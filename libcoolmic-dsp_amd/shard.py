@@ -4,9 +4,11 @@ Independent capture streams are the unit of data parallelism: global stream s li
 rank s % N for its whole life (parameters, VU window, EQ state never migrate) and no
 data-path collective exists.  The only collective is the optional node-global VU of
 BASELINE config 5: one record of NODE_WORDS int64 per rank (cmhip_batch_vu_node_partial),
-combined with SUM over the first half and MAX over the second half -- two all-reduces
-on a few hundred bytes, latency bound (RCCL over xGMI with backend "nccl"; the same code
-runs over gloo on CPU tensors in the tests).
+combined with SUM over the first half and MAX over the second half.  The exchange is
+latency bound (a few hundred bytes over xGMI), so records of several blocks travel
+together: gather_node_records() moves B records per rank with ONE all-gather and combines
+them locally; combine_node_records() is the one-record form with two all-reduces (RCCL with
+backend "nccl"; the same code runs over gloo on CPU tensors in the tests).
 """
 
 NODE_WORDS = 34
@@ -37,6 +39,27 @@ def combine_node_records(dist, words):
     dist.all_reduce(words[:NODE_SUM_WORDS], op=dist.ReduceOp.SUM)
     dist.all_reduce(words[NODE_SUM_WORDS:], op=dist.ReduceOp.MAX)
     return words
+
+
+def gather_node_records(dist, records, scratch=None):
+    """records: int64 tensor [B, NODE_WORDS] of this rank (B blocks).  One all-gather, then the
+    combine on the local device: -> [B, NODE_WORDS], sums added and keys maximised over the ranks.
+    (keys are below 2^63, so the signed maximum is the unsigned one.)"""
+    import torch
+    if records.dim() != 2 or records.shape[1] != NODE_WORDS:
+        raise ValueError("node records must be [B, %d]" % NODE_WORDS)
+    world = dist.get_world_size()
+    if scratch is None or tuple(scratch.shape) != (world,) + tuple(records.shape):
+        scratch = torch.empty((world,) + tuple(records.shape), dtype=records.dtype, device=records.device)
+    if records.is_cuda:
+        dist.all_gather_into_tensor(scratch, records)
+    else:                                            # gloo: the list form
+        parts = [scratch[r] for r in range(world)]
+        dist.all_gather(parts, records)
+    out = torch.empty_like(records)
+    out[:, :NODE_SUM_WORDS] = scratch[:, :, :NODE_SUM_WORDS].sum(dim=0)
+    out[:, NODE_SUM_WORDS:] = scratch[:, :, NODE_SUM_WORDS:].max(dim=0).values
+    return out
 
 
 def max_over_ranks(dist, seconds, device=None):

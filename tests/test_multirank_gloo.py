@@ -75,6 +75,12 @@ def _worker(rank, world, port, out):
         shard.combine_node_records(dist, words)
         rc, r = cm.node_finish(words.numpy(), C)
         assert rc == 0
+        # the batched form: several blocks' records in one all-gather, same result per block
+        mine_rec = torch.from_numpy(_node_record(orc, mine))
+        batch = torch.stack([mine_rec, torch.zeros_like(mine_rec), mine_rec])
+        comb = shard.gather_node_records(dist, batch)
+        assert torch.equal(comb[0], words) and torch.equal(comb[2], words)
+        assert int(comb[1].abs().sum()) == 0
         if rank == 0:
             out.put(r.as_dict())
     finally:
