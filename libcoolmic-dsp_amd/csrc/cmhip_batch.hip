@@ -308,6 +308,8 @@ static int batch_init(cmhip_batch_t *b)
         b->own_stream = true;
     }
     b->stride = (d.max_frames * d.channels + 7) / 8 * 8;
+    if (d.flags & CMHIP_EQ)                // rows of whole 8-frame chunks: the EQ kernel loads chunks
+        b->stride = (d.max_frames + 7) / 8 * 8 * d.channels;
     b->plane = (d.max_frames + 63) / 64 * 64;
 
     const size_t pcm_bytes = S * b->stride * sizeof(int16_t);

@@ -993,9 +993,11 @@ __device__ __forceinline__ int f32_to_i16(float y)
 #endif
 
 // Channels: a "row" is one channel of one stream -- every channel runs its stream's filter
-// with state of its own -- and a workgroup takes G / C whole streams (MONO: the 16-byte
-// vector loads and packed stores of config 3; otherwise the T lanes gather their channel's
-// samples with 16-bit loads through the stream's channel map and the S lanes scatter them).
+// with state of its own -- and a workgroup takes G / C whole streams.  CH = 1: mono, the 16-byte
+// vector loads and packed stores of config 3; CH = 2: stereo, two vector loads per chunk and one
+// v_perm_b32 per sample pair pick the row's channel (through the stream's channel map); CH = 0:
+// any count, the T lanes gather their channel's samples with 16-bit loads.  For CH != 1 the S
+// lanes scatter the int16 result into the interleaved frames.
 //
 // Wave order.  Waves w, w+4 and w+8 of a workgroup share a SIMD, and a step lasts as long as
 // the most loaded SIMD needs (issue slots plus the time its waves are blocked on LDS writes):
@@ -1057,10 +1059,11 @@ __device__ __forceinline__ u32 eq_role(u32 wave)
     }
 }
 
-template <int NSEC, int G, int NSW, bool MONO>
+template <int NSEC, int G, int NSW, int CH>
 __global__ __launch_bounds__((eq_waves<NSEC, G, NSW>() * 64))
 void k_eq_pipe(EqArgs a)
 {
+    constexpr bool MONO = CH == 1, STEREO = CH == 2;
     static_assert(G == 32, "the wave order below is laid out for 32 rows per workgroup");
     constexpr u32 EP_TB = 64;                     // frames per block
     constexpr u32 EP_ROW = EP_TB + 4;             // floats per LDS row
@@ -1080,7 +1083,7 @@ void k_eq_pipe(EqArgs a)
     extern __shared__ float lds[];                // NBUF buffers x 2 slots x EP_TILE floats, then G counts
     u32 *nfr_lds = reinterpret_cast<u32 *>(lds + NBUF * 2 * EP_TILE);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const u32 C = MONO ? 1u : a.channels;
+    const u32 C = MONO ? 1u : STEREO ? 2u : a.channels;
     const u32 SPG = G / C;                                // whole streams of this workgroup
     const u32 s0 = blockIdx.x * SPG;
     // row r of the workgroup: channel r % C of stream s0 + r / C
@@ -1210,22 +1213,31 @@ void k_eq_pipe(EqArgs a)
     // global memory inside the loop, so the compiler can wait with vmcnt(1) for the older
     // block instead of draining the queue; the stores have a wave of their own.
     const int16_t *l_src = a.in + (u64)l_s * a.stride;
-    const u32 l_last = (u32)a.stride - (MONO ? 8u : 1u);
-    auto fetch = [&](u32 b) -> u32x4 {
+    // (EQ batches have rows of whole 8-frame chunks, so a chunk with a valid frame is never clamped)
+    const u32 l_last = (u32)a.stride - (MONO ? 8u : STEREO ? 16u : 1u);
+    const u32 l_sel = l_m ? 0x07060302u : 0x05040100u;    // STEREO: which halves of two frames make a pair
+    struct Pcm { u32x4 a, b; };                           // a chunk in flight (b: second half, STEREO only)
+    auto fetch = [&](u32 b) -> Pcm {
         const u32 f0 = b * EP_TB + l_t8;
-        if (CMHIP_EQ_ABL & 2)
-            return u32x4{f0, f0 * 3u, f0 * 5u, f0 * 7u};
-        if constexpr (MONO) {
-            return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(l_src + min(f0, l_last)));
+        Pcm r = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        if (CMHIP_EQ_ABL & 2) {
+            r.a = u32x4{f0, f0 * 3u, f0 * 5u, f0 * 7u};
+        } else if constexpr (MONO) {
+            r.a = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(l_src + min(f0, l_last)));
+        } else if constexpr (STEREO) {                    // 8 frames x (L, R): 32 bytes
+            const u32x4 *p = reinterpret_cast<const u32x4 *>(l_src + min(2u * f0, l_last));
+            r.a = __builtin_nontemporal_load(p);
+            r.b = __builtin_nontemporal_load(p + 1);
         } else {
             u32 h[8];                                     // frames f0..f0+7 of input channel l_m
 #pragma unroll
             for (u32 k = 0; k < 8; k++)
                 h[k] = *reinterpret_cast<const uint16_t *>(l_src + min((f0 + k) * C + l_m, l_last));
-            return u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+            r.a = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
         }
+        return r;
     };
-    u32x4 wa = {0, 0, 0, 0}, wb = {0, 0, 0, 0};           // blocks of even / odd steps
+    Pcm wa = {{0, 0, 0, 0}, {0, 0, 0, 0}}, wb = wa;       // blocks of even / odd steps
     if (is_tin) {
         wa = fetch(0);
         wb = fetch(1);
@@ -1322,7 +1334,7 @@ void k_eq_pipe(EqArgs a)
     };
     float keep1 = 0.f, keep2 = 0.f;                       // section 0's new x1 / x2, if seen
     bool has1 = false, has2 = false;
-    auto tin_step = [&](u32x4 &wcur, const u32 step) {
+    auto tin_step = [&](Pcm &wcur, const u32 step) {
         if (!(CMHIP_EQ_ABL & 128)) {
 #ifdef CMHIP_EQ_STAMPS
             const u64 st_tt = __builtin_readcyclecounter();
@@ -1334,8 +1346,16 @@ void k_eq_pipe(EqArgs a)
                 const u32 b = step;
                 const u32 f0 = b * EP_TB + l_t8;
                 const bool have = f0 < l_n;               // beyond the end of the stream: zeros
-                const u32 w[4] = {have ? wcur.x : 0u, have ? wcur.y : 0u, have ? wcur.z : 0u,
-                                  have ? wcur.w : 0u};    // (a chunk the stream ends in keeps what
+                u32 w[4] = {wcur.a.x, wcur.a.y, wcur.a.z, wcur.a.w};
+                if constexpr (STEREO) {                   // this row's channel of the eight frames
+                    w[0] = __builtin_amdgcn_perm(wcur.a.y, wcur.a.x, l_sel);
+                    w[1] = __builtin_amdgcn_perm(wcur.a.w, wcur.a.z, l_sel);
+                    w[2] = __builtin_amdgcn_perm(wcur.b.y, wcur.b.x, l_sel);
+                    w[3] = __builtin_amdgcn_perm(wcur.b.w, wcur.b.z, l_sel);
+                }
+#pragma unroll
+                for (u32 q = 0; q < 4; q++)
+                    w[q] = have ? w[q] : 0u;              // (a chunk the stream ends in keeps what
                 wcur = fetch(b + 2);                      // follows in the row: never stored)
 #ifdef CMHIP_EQ_STAMPS
                 u32 stw = w[0];
@@ -1679,21 +1699,21 @@ static constexpr size_t eq_pipe_lds_bytes()
     return ((size_t)(2 * NSEC) * 2 * G * (64 + 4)) * sizeof(float) + G * sizeof(u32);
 }
 
-template <int NSEC, int G, int NSW, bool MONO>
+template <int NSEC, int G, int NSW, int CH>
 static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
 {
     constexpr size_t lds_bytes = eq_pipe_lds_bytes<NSEC, G>();
     static_assert(lds_bytes <= 160 * 1024, "tiles of a workgroup must fit the LDS");
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G, NSW, MONO>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G, NSW, CH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess)
             return e;
         configured = true;
     }
-    const u32 spg = MONO ? G : G / a.channels;            // whole streams per workgroup
-    hipLaunchKernelGGL((k_eq_pipe<NSEC, G, NSW, MONO>), dim3((a.streams + spg - 1) / spg),
+    const u32 spg = CH == 1 ? G : G / a.channels;         // whole streams per workgroup
+    hipLaunchKernelGGL((k_eq_pipe<NSEC, G, NSW, CH>), dim3((a.streams + spg - 1) / spg),
                        dim3(eq_waves<NSEC, G, NSW>() * 64), lds_bytes, st, a);
     return hipGetLastError();
 }
@@ -1706,8 +1726,10 @@ static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st)
     // the int16 conversion and the VU window are per-sample work of the S waves: more of them
     const bool heavy = a.out || a.vu;
     if (a.channels == 1)
-        return heavy ? launch_eq_pipe<NSEC, 32, 4, true>(a, st) : launch_eq_pipe<NSEC, 32, 1, true>(a, st);
-    return heavy ? launch_eq_pipe<NSEC, 32, 4, false>(a, st) : launch_eq_pipe<NSEC, 32, 1, false>(a, st);
+        return heavy ? launch_eq_pipe<NSEC, 32, 4, 1>(a, st) : launch_eq_pipe<NSEC, 32, 1, 1>(a, st);
+    if (a.channels == 2 && a.stride >= 16 && a.stride % 16 == 0)
+        return heavy ? launch_eq_pipe<NSEC, 32, 4, 2>(a, st) : launch_eq_pipe<NSEC, 32, 1, 2>(a, st);
+    return heavy ? launch_eq_pipe<NSEC, 32, 4, 0>(a, st) : launch_eq_pipe<NSEC, 32, 1, 0>(a, st);
 }
 
 hipError_t launch_eq(const EqArgs &a, hipStream_t st)
