@@ -963,23 +963,27 @@ __device__ __forceinline__ int f32_to_i16(float y)
 //   recurrence    y[t] = fma(-a1, y[t-1], fma(-a2, y[t-2], f[t]))       two dependent FMAs
 //
 // which is the oracle's Direct Form I in the same operation order.  A workgroup owns G
-// streams and walks them in 64-frame blocks, one __syncthreads() per block, with two kinds
-// of waves that hand 64-frame rows to each other through double-buffered LDS tiles:
+// rows (a row = one channel of one stream) and walks them in 64-frame blocks, one
+// __syncthreads() per block, with waves of four roles that hand 64-frame rows to each other
+// through double-buffered LDS tiles:
 //
-//   T waves (lane = stream row x 8-frame chunk; time-parallel, G/8 of them):
+//   T-in waves (lane = row x 8-frame chunk; time-parallel, G/8 of them):
 //     global load (two blocks ahead) -> gain -> float -> feed-forward of section 0 -> F_0
+//   T-ff waves (same lane shape, G/2 rows each in passes of 8 rows):
 //     Y_k-1 -> feed-forward of section k -> F_k               (k = 1 .. NSEC-1)
-//     Y_last -> coalesced non-temporal global stores
 //     x[t-1], x[t-2] of a chunk come from the neighbouring lane by DPP (row_shr:1), those
 //     of a block's first chunk from the last chunk of the previous step (row_shl:7).
-//   R waves (lane = section x stream; 64/G sections side by side, sequential in time):
-//     F_k -> the two dependent FMAs per sample -> Y_k
+//   R waves (lane = section x row; 64/G sections side by side, sequential in time):
+//     F_k (loaded into registers a step ahead) -> the two dependent FMAs per sample -> Y_k
+//   S work: Y_last -> coalesced non-temporal global stores (float planes), and for an int16
+//     result / VU window the conversion and the window of it; dealt out over R and T-ff waves
+//     (float planes only) or done by S waves of their own -- see eq_role() below.
 //
 // Measured on MI355X (tools/ubench_chain.hip, ubench_lds*.hip): a wave alone issues one
 // VALU op per ~4.3 clk, a dependent one after ~8; ds_read_b128 costs a wave ~5-10 clk to
 // issue, ds_write_b128 ~24 (50 when four waves write at once).  So the only waves that are
-// long per step are the R waves (16 reads, 128 FMAs, 16 writes); everything without a
-// recurrence is spread over T lanes, where a 64-frame row costs 2 reads + 2 writes.
+// long per step by themselves are the R waves (16 reads, 128 FMAs, 16 writes); everything
+// without a recurrence is spread over T lanes, where a 64-frame row costs 2 reads + 2 writes.
 // Rows are 68 floats (16-byte aligned, lane-per-row b128 access without bank conflicts).
 
 #ifndef CMHIP_EQ_RLAG
