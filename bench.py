@@ -70,9 +70,18 @@ def main():
                      "python -m torch.distributed.run --nproc-per-node %d ..." % (args.gpus, args.gpus))
         args.gpus = world
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+    # torch is plumbing for the multi-rank run only (rendezvous, RCCL, the clock over ranks).  A
+    # single rank does not load it: torch brings its own HIP runtime (ROCm 7.0 inside the wheel),
+    # and under that runtime's default direct dispatch the submitting thread of this step loop was
+    # seen stalling for a kernel's length per step on busy hosts (0.7 ms per step instead of 0.37;
+    # DESIGN.md section 5).  With torch loaded, AMD_DIRECT_DISPATCH=0 avoids that (0.40 ms).
+    force_node = os.environ.get("COOLMIC_BENCH_FORCE_NODE") == "1"       # single-rank test of the reduce path
+    need_torch = world > 1 or force_node
+    torch = dist = None
+    if need_torch:
+        os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
+        import torch
+        import torch.distributed as dist
 
     import __graft_entry__ as ge
     cm = ge.load_package()
@@ -85,9 +94,9 @@ def main():
     rehearsal = os.environ.get("COOLMIC_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    force_node = os.environ.get("COOLMIC_BENCH_FORCE_NODE") == "1"       # single-rank test of the reduce path
-    if world > 1 or force_node:
+    if need_torch:
+        torch.cuda.set_device(local_rank)
+    if need_torch:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29599")
         if rehearsal:
@@ -137,7 +146,7 @@ def main():
     # the host never waits inside the loop.
     node_on = node_vu and (world > 1 or force_node)
     NB = max(1, args.node_batch)
-    node_sets = [torch.zeros(NB, cm.NODE_WORDS, dtype=torch.int64, device="cuda") for _ in range(2)] if node_vu else None
+    node_sets = [torch.zeros(NB, cm.NODE_WORDS, dtype=torch.int64, device="cuda") for _ in range(2)] if node_on else None
     node_scratch = torch.empty(world, NB, cm.NODE_WORDS, dtype=torch.int64,
                                device="cpu" if rehearsal else "cuda") if node_on else None
     node_host = torch.zeros(NB, cm.NODE_WORDS, dtype=torch.int64) if node_on and rehearsal else None
@@ -160,18 +169,27 @@ def main():
             node_result[0] = shard.gather_node_records(dist, words, node_scratch)
             ev_done[k].record(cur)
 
+    def device_sync():
+        cm.device_synchronize(local_rank)       # hipDeviceSynchronize: every stream of this rank's GPU
+        if need_torch:
+            torch.cuda.synchronize()
+
     def barrier():
-        torch.cuda.synchronize()
+        device_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     def run_steps(n):
         # order per step: launch, snapshot of this window (async), then the host finishes the
         # PREVIOUS window -- the next launch is always queued before the host blocks
         pending = False
+        probe = os.environ.get("COOLMIC_BENCH_PROBE") == "1"
+        acc = [0.0, 0.0, 0.0]
         for _ in range(n):
+            tp0 = time.perf_counter()
             b.run(T)
+            tp1 = time.perf_counter()
             if node_on:
                 i = node_step[0]
                 node_step[0] += 1
@@ -183,9 +201,16 @@ def main():
                     node_exchange(k)
             if has_vu:
                 b.vu_snapshot()                      # async D2H of all windows + reset
+                tp2 = time.perf_counter()
                 if pending:
                     b.vu_collect(results, rcs)       # dB finish of the previous window (host)
                 pending = True
+                if probe:
+                    tp3 = time.perf_counter()
+                    acc[0] += tp1 - tp0; acc[1] += tp2 - tp1; acc[2] += tp3 - tp2
+        if probe and n:
+            print("probe: per step run %.0f us, snapshot %.0f us, collect %.0f us" %
+                  tuple(v / n * 1e6 for v in acc), file=sys.stderr)
         if pending:
             b.vu_collect(results, rcs)
         if node_on and node_step[0] % NB:              # records of a partly filled set
@@ -339,7 +364,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.workload, Cn)
 
-    if world > 1 or force_node:
+    if need_torch:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -63,6 +63,7 @@ typedef struct cmhip_batch_desc {
 
 /* ---- process level ------------------------------------------------------- */
 int          cmhip_device_count(void);            /* 0 without a usable GPU */
+int          cmhip_device_synchronize(int device); /* everything queued on that device has finished */
 const char  *cmhip_last_error(void);              /* per-thread text of the last failure */
 const char  *cmhip_version(void);
 

@@ -72,6 +72,7 @@ _vp = C.c_void_p
 SIGNATURES = {
     # include/coolmic_hip.h
     "cmhip_device_count": (C.c_int, []),
+    "cmhip_device_synchronize": (C.c_int, [C.c_int]),
     "cmhip_last_error": (C.c_char_p, []),
     "cmhip_version": (C.c_char_p, []),
     "cmhip_batch_new": (_vp, [_P(BatchDesc)]),
@@ -192,6 +193,10 @@ def _check(what, rc):
 
 def device_count():
     return lib.cmhip_device_count()
+
+
+def device_synchronize(device=0):
+    _check("device_synchronize", lib.cmhip_device_synchronize(device))
 
 
 def last_error():

@@ -1,7 +1,7 @@
 // cmhip_batch.hip -- the batch engine behind include/coolmic_hip.h.
 //
 // Host side of the MI355X path: owns the HBM slots of S streams, the per-stream
-// parameter table and the VU windows, launches the kernels of cmhip_kernels.hip on
+// parameter table and the VU windows, launches the kernels of k_block.hip / k_eq.hip / k_misc.hip on
 // one HIP stream and finishes VU windows on the host in double, exactly as the
 // reference does (ref: src/vumeter.c:189-218).  There is no CPU fallback: without a
 // device cmhip_batch_new() fails.
@@ -61,6 +61,15 @@ extern "C" int cmhip_device_count(void)
     return n;
 }
 
+extern "C" int cmhip_device_synchronize(int device)
+{
+    if (device < 0 || device >= cmhip_device_count())
+        return fail(COOLMIC_ERROR_INVAL, "device_synchronize: no HIP device %d", device);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return COOLMIC_ERROR_NONE;
+}
+
 // ---------------------------------------------------------------------------
 // the batch object
 
@@ -75,19 +84,24 @@ struct EventPair {
 // channel and stream): with thousands of streams per batch one host thread would take
 // about as long as the GPU needs for the next block.
 struct FinishPool {
+    // Helpers for the host-side dB finish of many windows.  Work is handed out in small chunks
+    // from a shared counter and the calling thread works too, so a helper that the OS does not
+    // schedule in time (busy hosts, CPU quotas) costs nothing: whoever runs takes the chunks.
+    static constexpr unsigned CHUNK = 64;
     std::vector<std::thread> workers;
     std::mutex m;
     std::condition_variable cv_work, cv_done;
-    unsigned generation = 0, remaining = 0;
+    unsigned generation = 0, active = 0;
     bool stop = false;
     void (*fn)(void *, unsigned, unsigned) = nullptr;
     void *arg = nullptr;
     unsigned total = 0;
+    std::atomic<unsigned> next{0};
 
     explicit FinishPool(unsigned n)
     {
         for (unsigned i = 0; i < n; i++)
-            workers.emplace_back([this, i, n] { loop(i, n); });
+            workers.emplace_back([this] { loop(); });
     }
     ~FinishPool()
     {
@@ -99,7 +113,16 @@ struct FinishPool {
         for (auto &t : workers)
             t.join();
     }
-    void loop(unsigned idx, unsigned n)
+    void drain(void (*f)(void *, unsigned, unsigned), void *a, unsigned tot)
+    {
+        for (;;) {
+            const unsigned lo = next.fetch_add(CHUNK, std::memory_order_relaxed);
+            if (lo >= tot)
+                return;
+            f(a, lo, lo + CHUNK < tot ? lo + CHUNK : tot);
+        }
+    }
+    void loop()
     {
         unsigned seen = 0;
         for (;;) {
@@ -115,28 +138,30 @@ struct FinishPool {
                 f = fn;
                 a = arg;
                 tot = total;
+                active++;
             }
-            const unsigned lo = (unsigned)((uint64_t)tot * idx / n);
-            const unsigned hi = (unsigned)((uint64_t)tot * (idx + 1) / n);
-            if (hi > lo)
-                f(a, lo, hi);
+            drain(f, a, tot);
             {
                 std::lock_guard<std::mutex> g(m);
-                if (--remaining == 0)
+                if (--active == 0)
                     cv_done.notify_one();
             }
         }
     }
     void run(void (*f)(void *, unsigned, unsigned), void *a, unsigned tot)
     {
-        std::unique_lock<std::mutex> g(m);
-        fn = f;
-        arg = a;
-        total = tot;
-        remaining = (unsigned)workers.size();
-        generation++;
+        {
+            std::lock_guard<std::mutex> g(m);
+            fn = f;
+            arg = a;
+            total = tot;
+            next.store(0, std::memory_order_relaxed);
+            generation++;
+        }
         cv_work.notify_all();
-        cv_done.wait(g, [&] { return remaining == 0; });
+        drain(f, a, tot);                             // the caller works as well
+        std::unique_lock<std::mutex> g(m);            // chunks taken by helpers may still be running
+        cv_done.wait(g, [&] { return active == 0; });
     }
 };
 

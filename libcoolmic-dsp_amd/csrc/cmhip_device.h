@@ -1,0 +1,224 @@
+// cmhip_device.h -- device-side helpers shared by the kernel files: exact gain arithmetic on packed
+// int16, the VU window key, wave reductions.  (Included by k_block.hip, k_eq.hip, k_misc.hip.)
+#ifndef CMHIP_DEVICE_H
+#define CMHIP_DEVICE_H
+
+#include "cmhip_internal.h"
+#include <stdlib.h>
+
+namespace cmhip {
+
+using u32 = uint32_t;
+using u64 = unsigned long long;
+
+
+__device__ __forceinline__ u32 uniform(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// magnitude of trunc(x*g/scale) after saturation; sgn = 0 or -1
+__device__ __forceinline__ u32 gain_mag(int x, u32 g2, u32 magic, u32 shift, int &sgn)
+{
+    sgn = x >> 31;
+    const u32 ax = (u32)((x ^ sgn) - sgn);          // |x| <= 32768
+    const u32 n2 = __umul24(ax, g2);                // 2*|x|*gain < 2^32
+    const u32 qa = __umulhi(n2, magic) >> shift;    // floor(|x|*gain/scale)
+    const u32 lim = 32767u - (u32)sgn;              // 32767, or 32768 for negatives
+    return qa < lim ? qa : lim;
+}
+
+__device__ __forceinline__ u64 wave_sum(u64 v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ u64 wave_max(u64 v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const u64 w = __shfl_down(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ u64 make_key(u32 mag, u64 index, u32 neg)
+{
+    if (mag == 0)
+        return 0;
+    return ((u64)mag << KEY_ABS_SHIFT) | ((~index & KEY_IDX_MASK) << 1) | (u64)neg;
+}
+
+// ---------------------------------------------------------------------------
+// Fast path: mono and stereo, any stereo channel map, slots 16-byte aligned.
+//
+// Every integer VALU op costs about the same on gfx950 (tools/ubench_valu.hip: mul_hi,
+// mul_lo, 24-bit multiplies, packed-16 ops and three-operand ops all issue in ~4 cycles
+// per wave, only two-operand 32-bit adds and fp32 multiplies are quicker), so the kernel
+// is built to minimise the instruction count per sample: the two int16 halves of a dword
+// are handled by packed-16 instructions wherever no 32-bit intermediate is needed
+// (sign masks, magnitudes, saturation, sign restore, running maximum), and only the
+// exact division (24-bit multiply, mul_hi, shift) is done per sample.
+//
+// Peak tracking costs ~1 op per sample: per 16-byte vector a packed running maximum of
+// the magnitudes is folded into a per-lane key (magnitude, vector ordinal); which sample
+// of the winning vector came first, and its sign, is found once per wave by looking at
+// that one vector again (locate_peak).
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32 pk_sign(u32 w)          // 0xffff in each negative half
+{
+    v2s v = __builtin_bit_cast(v2s, w);
+    v = v >> (short)15;
+    return __builtin_bit_cast(u32, v);
+}
+__device__ __forceinline__ u32 pk_sub(u32 a, u32 b)
+{
+    v2u x = __builtin_bit_cast(v2u, a) - __builtin_bit_cast(v2u, b);
+    return __builtin_bit_cast(u32, x);
+}
+__device__ __forceinline__ u32 pk_min(u32 a, u32 b)
+{
+    v2u x = __builtin_elementwise_min(__builtin_bit_cast(v2u, a), __builtin_bit_cast(v2u, b));
+    return __builtin_bit_cast(u32, x);
+}
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b)
+{
+    v2u x = __builtin_elementwise_max(__builtin_bit_cast(v2u, a), __builtin_bit_cast(v2u, b));
+    return __builtin_bit_cast(u32, x);
+}
+
+// one dword = two samples: returns the packed magnitudes after gain + saturation,
+// `out` receives the packed signed result
+__device__ __forceinline__ u32 gain2(u32 w, u32 g2lo, u32 g2hi, u32 magic, u32 shift, u32 &out)
+{
+    const u32 sg = pk_sign(w);
+    const u32 aw = pk_sub(w ^ sg, sg);                       // |x| per half (u16, 32768 ok)
+    const u32 n0 = __umul24(aw & 0xffffu, g2lo);             // 2*|x|*gain < 2^32
+    const u32 n1 = __umul24(aw >> 16, g2hi);
+    const u32 q0 = __umulhi(n0, magic) >> shift;             // floor(|x|*gain/scale)
+    const u32 q1 = __umulhi(n1, magic) >> shift;
+    u32 qw = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pk_u16(q0, q1));   // saturates at 65535
+    qw = pk_min(qw, pk_sub(0x7fff7fffu, sg));                // 32767, or 32768 for negatives
+    out = pk_sub(qw ^ sg, sg);
+    return qw;
+}
+
+// sum of squares with as few 64-bit additions as exactness allows: three squares
+// (each <= 2^30) fit a u32
+struct PowAcc {
+    u64 total;
+    u32 part;
+    u32 n;
+    __device__ __forceinline__ void add(u32 mag)
+    {
+        part += mag * mag;
+        if (++n == 3)
+            flush();
+    }
+    // square of one 16-bit half of a packed pair added in a single v_mad_u32_u16
+    __device__ __forceinline__ void add_lo(u32 pair)
+    {
+        asm("v_mad_u32_u16 %0, %1, %1, %0 op_sel:[0,0,0,0]" : "+v"(part) : "v"(pair));
+        if (++n == 3)
+            flush();
+    }
+    __device__ __forceinline__ void add_hi(u32 pair)
+    {
+        asm("v_mad_u32_u16 %0, %1, %1, %0 op_sel:[1,1,0,0]" : "+v"(part) : "v"(pair));
+        if (++n == 3)
+            flush();
+    }
+    __device__ __forceinline__ void flush()
+    {
+        total += part;
+        part = 0;
+        n = 0;
+    }
+};
+
+template <int C>
+__device__ __forceinline__ void store_f32(float *f32s, u64 plane, u32 v, const u32 (&o)[4])
+{
+    constexpr float k = 1.0f / 32768.0f;                 // exact scaling == x / 32768.f
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        f[2 * i] = (float)(int)(short)(o[i] & 0xffffu) * k;
+        f[2 * i + 1] = (float)((int)o[i] >> 16) * k;
+    }
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    if constexpr (C == 1) {
+        // two 16-byte halves of one 32-byte run per lane: each instruction writes half of
+        // every line, so these stay ordinary stores and L2 merges them (non-temporal ones
+        // measured 20 % slower here; the stereo planes below write whole lines and gain 5 %)
+        f32x4 *p = reinterpret_cast<f32x4 *>(f32s + (u64)v * 8);
+        const f32x4 lo = {f[0], f[1], f[2], f[3]}, hi = {f[4], f[5], f[6], f[7]};
+        p[0] = lo;
+        p[1] = hi;
+    } else {
+        const f32x4 l = {f[0], f[2], f[4], f[6]}, r = {f[1], f[3], f[5], f[7]};
+        __builtin_nontemporal_store(l, reinterpret_cast<f32x4 *>(f32s + (u64)v * 4));
+        __builtin_nontemporal_store(r, reinterpret_cast<f32x4 *>(f32s + plane + (u64)v * 4));
+    }
+}
+
+// scalar form of the same arithmetic, used for the samples of a ragged tail
+__device__ __forceinline__ int gain1(int x, u32 g2, u32 magic, u32 shift, u32 &mag)
+{
+    int sg;
+    mag = gain_mag(x, g2, magic, shift, sg);
+    return (int)((mag ^ (u32)sg) - (u32)sg);
+}
+
+// value of another lane by DPP (0 where the source lane is outside the row)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// wave64 reductions on the VALU (DPP), result valid in lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp0(u32 v)       // lanes without a source read 0
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ u32 wave_max_u32(u32 v)
+{
+    v = max(v, dpp0<0x111, 0xf>(v));             // row_shr:1
+    v = max(v, dpp0<0x112, 0xf>(v));             // row_shr:2
+    v = max(v, dpp0<0x114, 0xf>(v));             // row_shr:4
+    v = max(v, dpp0<0x118, 0xf>(v));             // row_shr:8  -> lane 15 of each row
+    v = max(v, dpp0<0x142, 0xa>(v));             // row_bcast:15 into rows 1 and 3
+    v = max(v, dpp0<0x143, 0xc>(v));             // row_bcast:31 into rows 2 and 3
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ u32 wave_add_u32(u32 v)
+{
+    v += dpp0<0x111, 0xf>(v);
+    v += dpp0<0x112, 0xf>(v);
+    v += dpp0<0x114, 0xf>(v);
+    v += dpp0<0x118, 0xf>(v);
+    v += dpp0<0x142, 0xa>(v);
+    v += dpp0<0x143, 0xc>(v);
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+// 64-bit sum of per-lane values below 2^40, as two 32-bit reductions
+__device__ __forceinline__ u64 wave_add_u40(u64 v)
+{
+    const u32 lo = wave_add_u32((u32)v & 0xffffffu);          // 64 * 2^24 fits
+    const u32 hi = wave_add_u32((u32)(v >> 24));              // 64 * 2^16 fits
+    return (u64)lo + ((u64)hi << 24);
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// the tile of the hot kernel (and of the plain-copy ceilings that mirror its access shape)
+constexpr u32 TILE_U = 4;                        // 16-byte vectors per lane when PCM is written
+constexpr u32 TILE_VEC = 64 * TILE_U;            // vectors per wave: 4 KiB of PCM
+
+}  // namespace cmhip
+#endif

@@ -1,5 +1,5 @@
 // cmhip_internal.h -- device-side records and launcher prototypes shared by
-// cmhip_kernels.hip (the gfx950 kernels) and cmhip_batch.hip (the engine).
+// k_block.hip / k_eq.hip / k_misc.hip (the gfx950 kernels) and cmhip_batch.hip (the engine).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -97,7 +97,7 @@ struct GenArgs {
     int16_t  sine[48];
 };
 
-// launchers (cmhip_kernels.hip)
+// launchers (k_block.hip, k_eq.hip, k_misc.hip)
 hipError_t launch_run(const RunArgs &a, hipStream_t st);
 hipError_t launch_eq(const EqArgs &a, hipStream_t st);
 hipError_t launch_generate(const GenArgs &a, int mode, hipStream_t st);

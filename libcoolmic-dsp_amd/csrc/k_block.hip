@@ -1,0 +1,731 @@
+// k_block.hip -- gfx950 (MI355X, wave64) block kernels of the transform -> vumeter path:
+// k_run_fast (mono, stereo), k_run_wide (4, 8 channels), k_run_rows (any count, channel maps).
+//
+// Everything here is pointwise + reduction over packed int16, so the bound is HBM
+// bandwidth (no MFMA).  Design rules followed (cdna_hip_programming.md G11-G13,
+// Appendix B "Reduction"):
+//   * 16 bytes per lane per load/store (global_load_dwordx4), 1 KiB per wave
+//     instruction, four loads in flight per lane before the first use;
+//   * a wave owns a contiguous chunk of ONE stream, so stream parameters live in
+//     SGPRs and there is no barrier and no LDS traffic in the hot kernel;
+//   * exact integer arithmetic only: 24-bit multiplies, one mul_hi for the division,
+//     64-bit integer atomics for the VU window (order independent => bit exact).
+//
+// Reference semantics restated (never copied):
+//   gain     ref: src/transform.c:101-124   q = trunc(x*g/scale) saturated
+//   VU       ref: src/vumeter.c:161-177     first max-|x| peak, sum of squares
+//   float    ref: src/enc_vorbis.c:108-115  x / 32768.f, planar
+#include "cmhip_device.h"
+
+namespace cmhip {
+
+// read-only runs take bigger tiles to amortise the epilogue (picked per channel count from
+// interleaved A/B runs, tools/ab_tiles.py); $CMHIP_VU_TILE (4, 8, 16) overrides for tuning
+constexpr u32 TILE_U_VUONLY_MONO = 8;
+constexpr u32 TILE_U_VUONLY_STEREO = 16;
+
+// One wave = one 4 KiB tile of one stream, one pass: four non-temporal 16-byte loads per
+// lane, arithmetic, four non-temporal stores, then a short epilogue.  Short-lived waves
+// over small tiles keep the chip-wide access window compact; on MI355X that is worth
+// ~15 % of HBM bandwidth over waves that each stream through tens of KiB
+// (tools/ubench_copy*.hip: 6.3-6.5 TB/s against 5.0-5.4 TB/s for read+write).
+// FULL: the tile lies completely inside the stream's whole vectors -- no bounds tests, no
+// zero padding, no ragged tail; this is the case for all but the last tile of a stream.
+template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U, bool FULL>
+__device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 nsamp, u32 nfull, u32 ntail,
+                                          u64 base, VuState *vs)
+{
+    constexpr u32 TILE_U = U;
+    constexpr u32 TILE_VEC = 64 * TILE_U;
+    const u32 lane = threadIdx.x;
+    const u32 v0 = k * TILE_VEC;
+    (void)nsamp;
+
+    const StreamParam *p = a.param + s;
+    const u32 magic = p->magic, shift = p->shift, perm2 = p->perm2;
+    const u32 g2lo = p->gain2[0], g2hi = p->gain2[C - 1];    // gains of the two dword halves
+
+    const int16_t *ins = a.in + (u64)s * a.stride;
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(ins);
+    int16_t *outs = WRITE_PCM ? a.out + (u64)s * a.stride : nullptr;
+    u32x4 *dst = reinterpret_cast<u32x4 *>(outs);
+    float *f32s = WRITE_F32 ? a.f32 + (u64)s * a.plane * C : nullptr;
+
+    // ---- load: everything this lane will touch, before anything is stored (in-place safe)
+    u32 x[TILE_U][4];
+    bool full[TILE_U], tail[TILE_U];
+#pragma unroll
+    for (u32 u = 0; u < TILE_U; u++) {
+        const u32 v = v0 + 64u * u + lane;
+        full[u] = FULL || v < nfull;
+        tail[u] = !FULL && ntail && v == nfull;
+        u32x4 w = {0, 0, 0, 0};
+        if (full[u])
+            w = __builtin_nontemporal_load(src + v);
+        x[u][0] = w.x; x[u][1] = w.y; x[u][2] = w.z; x[u][3] = w.w;
+        if (tail[u]) {                           // ragged end: sample by sample, zero padded
+            for (u32 j = 0; j < ntail; j++) {
+                const u32 val = (u32)(uint16_t)ins[(u64)v * 8 + j];
+#pragma unroll
+                for (u32 i = 0; i < 4; i++)
+                    if (i == (j >> 1))
+                        x[u][i] |= val << (16u * (j & 1u));
+            }
+        }
+    }
+
+    // ---- arithmetic
+    u32 qw[TILE_U][4];                           // packed magnitudes, kept for the epilogue
+    PowAcc pw[2] = {{0, 0, 0}, {0, 0, 0}};
+    u32 best[2] = {0, 0};                        // (magnitude << 16) | (U-1-u) << 6 | (63-lane)
+#pragma unroll
+    for (u32 u = 0; u < TILE_U; u++) {
+        const u32 v = v0 + 64u * u + lane;
+        u32 o[4], vmax = 0;
+#pragma unroll
+        for (u32 i = 0; i < 4; i++) {
+            if constexpr (C == 2)
+                x[u][i] = __builtin_amdgcn_perm(x[u][i], x[u][i], perm2);   // stereo channel map
+            qw[u][i] = gain2(x[u][i], g2lo, g2hi, magic, shift, o[i]);
+            if constexpr (DO_VU) {
+                vmax = pk_max(vmax, qw[u][i]);
+                pw[0].add_lo(qw[u][i]);
+                pw[C - 1].add_hi(qw[u][i]);
+            }
+        }
+        if constexpr (DO_VU) {
+            const u32 tag = ((TILE_U - 1u - u) << 6) | (63u - lane);
+            const u32 k0 = (vmax << 16) | tag;
+            const u32 k1 = (vmax & 0xffff0000u) | tag;
+            best[0] = max(best[0], k0);
+            best[1] = max(best[1], k1);
+        }
+        if (full[u]) {
+            if constexpr (WRITE_PCM) {
+                const u32x4 ov = {o[0], o[1], o[2], o[3]};
+                __builtin_nontemporal_store(ov, dst + v);
+            }
+            if constexpr (WRITE_F32)
+                store_f32<C>(f32s, a.plane, v, o);
+        } else if (tail[u]) {
+            for (u32 j = 0; j < ntail; j++) {
+                u32 ow = 0;
+#pragma unroll
+                for (u32 i = 0; i < 4; i++)
+                    if (i == (j >> 1))
+                        ow = o[i];
+                const int q = (int)(short)((ow >> (16u * (j & 1u))) & 0xffffu);
+                if constexpr (WRITE_PCM)
+                    outs[(u64)v * 8 + j] = (int16_t)q;
+                if constexpr (WRITE_F32)
+                    f32s[(u64)(j % (u32)C) * a.plane + ((u64)v * 8 + j) / (u32)C] = q * (1.0f / 32768.0f);
+            }
+        }
+    }
+
+    // ---- epilogue: one add and one max per channel into the stream's window
+    if constexpr (DO_VU) {
+        pw[0].flush();
+        pw[1].flush();
+        u64 sum[2];
+        u32 wkey[2];
+        if constexpr (C == 1) {
+            sum[0] = wave_add_u40(pw[0].total + pw[1].total);
+            wkey[0] = wave_max_u32(max(best[0], best[1]));
+            sum[1] = 0;
+            wkey[1] = 0;
+        } else {
+            sum[0] = wave_add_u40(pw[0].total);
+            sum[1] = wave_add_u40(pw[1].total);
+            wkey[0] = wave_max_u32(best[0]);
+            wkey[1] = wave_max_u32(best[1]);
+        }
+        u64 gkey[2] = {0, 0};
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const u32 mag = wkey[c] >> 16;
+            if (mag == 0)
+                continue;
+            // the winning vector: lowest ordinal, then lowest lane; fetch it into SGPRs
+            const u32 uw = TILE_U - 1u - ((wkey[c] >> 6) & (TILE_U - 1u));
+            const u32 lw = 63u - (wkey[c] & 63u);
+            u32 Q[4], X[4];
+#pragma unroll
+            for (u32 u = 0; u < TILE_U; u++) {
+                if (uw == u) {
+#pragma unroll
+                    for (u32 i = 0; i < 4; i++) {
+                        Q[i] = (u32)__builtin_amdgcn_readlane((int)qw[u][i], (int)lw);
+                        X[i] = (u32)__builtin_amdgcn_readlane((int)x[u][i], (int)lw);
+                    }
+                }
+            }
+            // first sample of this channel with that magnitude, and its sign
+            u32 first = 8, neg = 0;
+#pragma unroll
+            for (u32 j = 0; j < 8; j++) {
+                if (C == 2 && (j & 1u) != (u32)c)
+                    continue;
+                const u32 m = (Q[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
+                if (m == mag && first == 8) {
+                    first = j;
+                    neg = (X[j >> 1] >> (16u * (j & 1u) + 15u)) & 1u;
+                }
+            }
+            gkey[c] = make_key(mag, base + 8ull * (v0 + 64u * uw + lw) + first, neg);
+        }
+        if (lane < (u32)C) {
+            const u64 ssum = lane == 0 ? sum[0] : sum[1];
+            const u64 skey = lane == 0 ? gkey[0] : gkey[1];
+            if (ssum)
+                atomicAdd(&vs->power[lane], ssum);
+            if (skey)
+                atomicMax(&vs->key[lane], skey);
+        }
+    }
+}
+
+template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U>
+__global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
+{
+    constexpr u32 TILE_VEC = 64 * U;
+    const u32 lane = threadIdx.x;
+    const u32 s = blockIdx.x / a.chunks;         // stream
+    const u32 k = blockIdx.x - s * a.chunks;     // tile inside the stream
+
+    const u32 nfr = a.nframes ? a.nframes[s] : a.frames;
+    const u32 nsamp = nfr * (u32)C;
+    const u32 nfull = nsamp >> 3;                // whole 16-byte vectors
+    const u32 ntail = nsamp & 7u;                // samples in the partial last vector
+    const u32 v0 = k * TILE_VEC;
+
+    VuState *vs = DO_VU ? a.vu + s : nullptr;
+    u64 base = 0;
+    if constexpr (DO_VU) {
+        // window position: read from one slot, the stream's first tile writes the other
+        base = vs->samples[a.parity];
+        if (k == 0 && lane == 0)
+            vs->samples[a.parity ^ 1u] = base + nsamp;
+    }
+    if (v0 >= nfull + (ntail ? 1u : 0u))
+        return;
+    if (v0 + TILE_VEC <= nfull)
+        fast_tile<C, WRITE_PCM, WRITE_F32, DO_VU, U, true>(a, s, k, nsamp, nfull, ntail, base, vs);
+    else
+        fast_tile<C, WRITE_PCM, WRITE_F32, DO_VU, U, false>(a, s, k, nsamp, nfull, ntail, base, vs);
+}
+
+// ---------------------------------------------------------------------------
+// Wide path: 4 or 8 channels with the identity channel map (the template also covers 16,
+// which k_run_rows now serves faster).  Same tile scheme and the
+// same packed arithmetic as k_run_fast; a 16-byte vector holds 8/C frames, so every vector
+// position has a fixed channel (for 16 channels: fixed per lane parity) and the per-channel
+// accumulators live in registers.  NS = min(C, 8) accumulator slots per lane: the half h of
+// dword i feeds slot 2*(i % (NS/2)) + h.
+
+template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U>
+__global__ __launch_bounds__(64) void k_run_wide(RunArgs a)
+{
+    constexpr u32 TILE_U = U;
+    constexpr u32 TILE_VEC = 64 * TILE_U;
+    constexpr u32 NS = C < 8 ? C : 8;            // accumulator slots per lane
+    constexpr u32 NG = NS / 2;                   // dword groups
+    constexpr u32 NCLS = C == 16 ? 2 : 1;        // lane classes (vector parity) for 16 channels
+    const u32 lane = threadIdx.x;
+    const u32 s = blockIdx.x / a.chunks;
+    const u32 k = blockIdx.x - s * a.chunks;
+
+    const u32 nfr = a.nframes ? a.nframes[s] : a.frames;
+    const u32 nsamp = nfr * (u32)C;
+    const u32 nfull = nsamp >> 3;
+    const u32 ntail = nsamp & 7u;                // only possible for 4 channels (one frame)
+    const u32 v0 = k * TILE_VEC;
+
+    VuState *vs = DO_VU ? a.vu + s : nullptr;
+    u64 base = 0;
+    if constexpr (DO_VU) {
+        base = vs->samples[a.parity];
+        if (k == 0 && lane == 0)
+            vs->samples[a.parity ^ 1u] = base + nsamp;
+    }
+    if (v0 >= nfull + (ntail ? 1u : 0u))
+        return;
+
+    const StreamParam *p = a.param + s;
+    const u32 magic = p->magic, shift = p->shift;
+    const u32 cls = C == 16 ? (lane & 1u) : 0u;  // v0 and 64*u are even: vector parity = lane parity
+    u32 g2[NS];
+#pragma unroll
+    for (u32 i = 0; i < NS; i++)
+        g2[i] = p->gain2[i + 8u * cls];
+
+    const int16_t *ins = a.in + (u64)s * a.stride;
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(ins);
+    int16_t *outs = WRITE_PCM ? a.out + (u64)s * a.stride : nullptr;
+    u32x4 *dst = reinterpret_cast<u32x4 *>(outs);
+    float *f32s = WRITE_F32 ? a.f32 + (u64)s * a.plane * C : nullptr;
+
+    u32 x[TILE_U][4];
+    bool full[TILE_U], tail[TILE_U];
+#pragma unroll
+    for (u32 u = 0; u < TILE_U; u++) {
+        const u32 v = v0 + 64u * u + lane;
+        full[u] = v < nfull;
+        tail[u] = ntail && v == nfull;
+        u32x4 w = {0, 0, 0, 0};
+        if (full[u])
+            w = __builtin_nontemporal_load(src + v);
+        x[u][0] = w.x; x[u][1] = w.y; x[u][2] = w.z; x[u][3] = w.w;
+        if (tail[u]) {
+            for (u32 j = 0; j < ntail; j++) {
+                const u32 val = (u32)(uint16_t)ins[(u64)v * 8 + j];
+#pragma unroll
+                for (u32 i = 0; i < 4; i++)
+                    if (i == (j >> 1))
+                        x[u][i] |= val << (16u * (j & 1u));
+            }
+        }
+    }
+
+    u32 qw[TILE_U][4];
+    PowAcc pw[NS];
+    u32 best[NS];
+#pragma unroll
+    for (u32 i = 0; i < NS; i++) {
+        pw[i] = PowAcc{0, 0, 0};
+        best[i] = 0;
+    }
+#pragma unroll
+    for (u32 u = 0; u < TILE_U; u++) {
+        const u32 v = v0 + 64u * u + lane;
+        u32 o[4], vmax[NG];
+#pragma unroll
+        for (u32 g = 0; g < NG; g++)
+            vmax[g] = 0;
+#pragma unroll
+        for (u32 i = 0; i < 4; i++) {
+            constexpr u32 dummy = 0;
+            (void)dummy;
+            const u32 g = i % NG;
+            qw[u][i] = gain2(x[u][i], g2[2 * g], g2[2 * g + 1], magic, shift, o[i]);
+            if constexpr (DO_VU) {
+                vmax[g] = pk_max(vmax[g], qw[u][i]);
+                pw[2 * g].add_lo(qw[u][i]);
+                pw[2 * g + 1].add_hi(qw[u][i]);
+            }
+        }
+        if constexpr (DO_VU) {
+            const u32 tag = ((TILE_U - 1u - u) << 6) | (63u - lane);
+#pragma unroll
+            for (u32 g = 0; g < NG; g++) {
+                best[2 * g] = max(best[2 * g], (vmax[g] << 16) | tag);
+                best[2 * g + 1] = max(best[2 * g + 1], (vmax[g] & 0xffff0000u) | tag);
+            }
+        }
+        const u32 cnt = full[u] ? 8u : (tail[u] ? ntail : 0u);
+        if (full[u]) {
+            if constexpr (WRITE_PCM) {
+                const u32x4 ov = {o[0], o[1], o[2], o[3]};
+                __builtin_nontemporal_store(ov, dst + v);
+            }
+        } else if (tail[u]) {
+            if constexpr (WRITE_PCM) {
+                for (u32 j = 0; j < ntail; j++) {
+                    u32 ow = 0;
+#pragma unroll
+                    for (u32 i = 0; i < 4; i++)
+                        if (i == (j >> 1))
+                            ow = o[i];
+                    outs[(u64)v * 8 + j] = (int16_t)((ow >> (16u * (j & 1u))) & 0xffffu);
+                }
+            }
+        }
+        if constexpr (WRITE_F32) {
+            // planar float: consecutive lanes hold consecutive frames, so each of these
+            // stores writes a contiguous run of a plane
+#pragma unroll
+            for (u32 j = 0; j < 8; j++) {
+                if (j < cnt) {
+                    const u32 idx = v * 8u + j;
+                    const int q = (int)(short)((o[j >> 1] >> (16u * (j & 1u))) & 0xffffu);
+                    f32s[(u64)(idx % (u32)C) * a.plane + idx / (u32)C] = q * (1.0f / 32768.0f);
+                }
+            }
+        }
+    }
+
+    if constexpr (DO_VU) {
+#pragma unroll
+        for (u32 i = 0; i < NS; i++)
+            pw[i].flush();
+#pragma unroll
+        for (u32 c = 0; c < NCLS; c++) {
+            const bool mine = NCLS == 1 || cls == c;
+#pragma unroll
+            for (u32 sl = 0; sl < NS; sl++) {
+                const u64 sum = wave_add_u40(mine ? pw[sl].total : 0ull);
+                const u32 wkey = wave_max_u32(mine ? best[sl] : 0u);
+                const u32 ch = sl + 8u * c;
+                const u32 mag = wkey >> 16;
+                u64 gkey = 0;
+                if (mag) {
+                    const u32 uw = TILE_U - 1u - ((wkey >> 6) & (TILE_U - 1u));
+                    const u32 lw = 63u - (wkey & 63u);
+                    u32 Q[4], X[4];
+#pragma unroll
+                    for (u32 u = 0; u < TILE_U; u++) {
+                        if (uw == u) {
+#pragma unroll
+                            for (u32 i = 0; i < 4; i++) {
+                                Q[i] = (u32)__builtin_amdgcn_readlane((int)qw[u][i], (int)lw);
+                                X[i] = (u32)__builtin_amdgcn_readlane((int)x[u][i], (int)lw);
+                            }
+                        }
+                    }
+                    u32 first = 8, neg = 0;
+#pragma unroll
+                    for (u32 j = 0; j < 8; j++) {
+                        if (j % NS != sl)
+                            continue;
+                        const u32 m = (Q[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
+                        if (m == mag && first == 8) {
+                            first = j;
+                            neg = (X[j >> 1] >> (16u * (j & 1u) + 15u)) & 1u;
+                        }
+                    }
+                    gkey = make_key(mag, base + 8ull * (v0 + 64u * uw + lw) + first, neg);
+                }
+                if (lane == 0) {
+                    if (sum)
+                        atomicAdd(&vs->power[ch], sum);
+                    if (gkey)
+                        atomicMax(&vs->key[ch], gkey);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Row path: any channel count, identity channel map (3, 5, 6 = 5.1, 7, 9...16 channels; 1, 2,
+// 4 and 8 have the kernels above).  The channel of a sample is (8*v + j) mod C for
+// vector v and position j, which changes from vector to vector -- unless the vectors a lane
+// visits are a multiple of P = C / gcd(C, 8) apart.  So a wave walks ROWS of W = 64 - 64 % P
+// vectors (63, 60, 55 or 52 of the 64 lanes work): rows are contiguous, loads and stores stay
+// coalesced, and position j of a lane has the same channel in every row.  Gains and
+// per-position accumulators are then per-lane constants / registers, exactly the packed
+// arithmetic of the kernels above; only the final merge differs (positions of different
+// lanes hold different channels: LDS atomics by channel, once per wave).
+
+//
+// MAP: the streams carry channel maps.  A row holds whole frames, so a mapped sample's source
+// lies in the same row: the raw row goes through LDS and every position gathers its source
+// with a 16-bit read at a per-lane constant offset.
+
+template <bool WRITE_PCM, bool WRITE_F32, bool DO_VU, bool MAP>
+__global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_tile)
+{
+    constexpr u32 UR = 4;                        // rows in flight
+    __shared__ u64 lsum[MAX_CH];
+    __shared__ u64 lkey[MAX_CH];
+    __shared__ u32x4 raw[MAP ? UR * 64 : 1];     // the rows as loaded (MAP only)
+    const u32 lane = threadIdx.x;
+    const u32 s = blockIdx.x / a.chunks;
+    const u32 k = blockIdx.x - s * a.chunks;
+    const u32 C = a.channels;
+
+    const u32 nfr = a.nframes ? a.nframes[s] : a.frames;
+    const u32 nsamp = nfr * C;
+    const u32 nfull = nsamp >> 3;                // whole 16-byte vectors
+    const u32 ntail = nsamp & 7u;                // samples in the partial last vector
+    const u32 nvec = nfull + (ntail ? 1u : 0u);
+    const u32 row0 = k * rows_per_tile;
+
+    VuState *vs = DO_VU ? a.vu + s : nullptr;
+    u64 base = 0;
+    if constexpr (DO_VU) {
+        base = vs->samples[a.parity];
+        if (k == 0 && lane == 0)
+            vs->samples[a.parity ^ 1u] = base + nsamp;
+    }
+    if ((u64)row0 * W >= nvec)
+        return;
+    if constexpr (DO_VU) {
+        if (lane < MAX_CH) {
+            lsum[lane] = 0;
+            lkey[lane] = 0;
+        }
+    }
+
+    const StreamParam *p = a.param + s;
+    const u32 magic = p->magic, shift = p->shift;
+    const bool active = lane < W;
+    const u32 lane_fr = 8u * lane / C;           // whole frames before this lane's vector in a row
+    const u32 phase = 8u * lane - lane_fr * C;   // channel of its position 0
+    const u32 FW = 8u * W / C;                   // frames per row (8W is a multiple of C)
+    u32 ch[8], df[8], g2[8];
+    u32 so[8];                                   // MAP: byte offset of position j's source in its row
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+        const u32 t = phase + j;
+        df[j] = t / C;
+        ch[j] = t - df[j] * C;
+        g2[j] = p->gain2[ch[j]];
+        so[j] = MAP ? 2u * ((lane_fr + df[j]) * C + p->chmap[ch[j]]) : 0u;
+    }
+
+    const int16_t *ins = a.in + (u64)s * a.stride;
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(ins);
+    int16_t *outs = WRITE_PCM ? a.out + (u64)s * a.stride : nullptr;
+    u32x4 *dst = reinterpret_cast<u32x4 *>(outs);
+    float *f32s = WRITE_F32 ? a.f32 + (u64)s * a.plane * C : nullptr;
+
+    PowAcc pw[8];
+    u32 best[8];                                 // |peak| << 16 | (0x7fff - row in tile) << 1 | negative
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+        pw[j] = PowAcc{0, 0, 0};
+        best[j] = 0;
+    }
+
+    for (u32 r0 = 0; r0 < rows_per_tile; r0 += UR) {
+        if ((u64)(row0 + r0) * W >= nvec)
+            break;
+        u32 x[UR][4];
+        bool full[UR], tail[UR];
+#pragma unroll
+        for (u32 u = 0; u < UR; u++) {
+            const u32 v = (row0 + r0 + u) * W + lane;
+            full[u] = active && v < nfull;
+            tail[u] = active && ntail && v == nfull;
+            u32x4 w = {0, 0, 0, 0};
+            if (full[u])
+                w = __builtin_nontemporal_load(src + v);
+            x[u][0] = w.x; x[u][1] = w.y; x[u][2] = w.z; x[u][3] = w.w;
+            if (tail[u]) {
+                for (u32 j = 0; j < ntail; j++) {
+                    const u32 val = (u32)(uint16_t)ins[(u64)v * 8 + j];
+#pragma unroll
+                    for (u32 i = 0; i < 4; i++)
+                        if (i == (j >> 1))
+                            x[u][i] |= val << (16u * (j & 1u));
+                }
+            }
+        }
+        if constexpr (MAP) {
+            __syncthreads();                     // the previous rows have been gathered
+#pragma unroll
+            for (u32 u = 0; u < UR; u++)
+                raw[u * 64u + lane] = u32x4{x[u][0], x[u][1], x[u][2], x[u][3]};
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (u32 u = 0; u < UR; u++) {
+                    const unsigned char *rowb = reinterpret_cast<const unsigned char *>(raw + u * 64u);
+#pragma unroll
+                    for (u32 i = 0; i < 4; i++) {
+                        const u32 lo = *reinterpret_cast<const uint16_t *>(rowb + so[2 * i]);
+                        const u32 hi = *reinterpret_cast<const uint16_t *>(rowb + so[2 * i + 1]);
+                        x[u][i] = lo | (hi << 16);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (u32 u = 0; u < UR; u++) {
+            const u32 row = row0 + r0 + u;
+            const u32 v = row * W + lane;
+            u32 o[4];
+            const u32 tag = (0x7fffu - (r0 + u)) << 1;
+#pragma unroll
+            for (u32 i = 0; i < 4; i++) {
+                const u32 qw = gain2(x[u][i], g2[2 * i], g2[2 * i + 1], magic, shift, o[i]);
+                if constexpr (DO_VU) {
+                    best[2 * i] = max(best[2 * i], (qw << 16) | tag | ((x[u][i] >> 15) & 1u));
+                    best[2 * i + 1] = max(best[2 * i + 1], (qw & 0xffff0000u) | tag | (x[u][i] >> 31));
+                    pw[2 * i].add_lo(qw);
+                    pw[2 * i + 1].add_hi(qw);
+                }
+            }
+            if (full[u]) {
+                if constexpr (WRITE_PCM) {
+                    const u32x4 ov = {o[0], o[1], o[2], o[3]};
+                    __builtin_nontemporal_store(ov, dst + v);
+                }
+            } else if (tail[u]) {
+                if constexpr (WRITE_PCM) {
+                    for (u32 j = 0; j < ntail; j++) {
+                        u32 ow = 0;
+#pragma unroll
+                        for (u32 i = 0; i < 4; i++)
+                            if (i == (j >> 1))
+                                ow = o[i];
+                        outs[(u64)v * 8 + j] = (int16_t)((ow >> (16u * (j & 1u))) & 0xffffu);
+                    }
+                }
+            }
+            if constexpr (WRITE_F32) {
+                const u32 cnt = full[u] ? 8u : (tail[u] ? ntail : 0u);
+                const u32 fr = row * FW + lane_fr;
+#pragma unroll
+                for (u32 j = 0; j < 8; j++) {
+                    if (j < cnt) {
+                        const int q = (int)(short)((o[j >> 1] >> (16u * (j & 1u))) & 0xffffu);
+                        f32s[(u64)ch[j] * a.plane + fr + df[j]] = q * (1.0f / 32768.0f);
+                    }
+                }
+            }
+        }
+    }
+
+    if constexpr (DO_VU) {
+        __syncthreads();                         // accumulators cleared (one wave: cheap)
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) {
+            pw[j].flush();
+            if (pw[j].total)
+                atomicAdd(reinterpret_cast<unsigned long long *>(&lsum[ch[j]]), (unsigned long long)pw[j].total);
+            const u32 mag = best[j] >> 16;
+            if (mag) {
+                const u32 rr = 0x7fffu - ((best[j] >> 1) & 0x7fffu);
+                const u64 v = (u64)(row0 + rr) * W + lane;
+                const u64 key = make_key(mag, base + 8ull * v + j, best[j] & 1u);
+                atomicMax(reinterpret_cast<unsigned long long *>(&lkey[ch[j]]), (unsigned long long)key);
+            }
+        }
+        __syncthreads();
+        if (lane < C) {
+            if (lsum[lane])
+                atomicAdd(&vs->power[lane], lsum[lane]);
+            if (lkey[lane])
+                atomicMax(&vs->key[lane], lkey[lane]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Launcher of the block kernels: by channel count and by what the batch asks for.
+
+hipError_t launch_run(const RunArgs &a, hipStream_t st)
+{
+    const bool pcm = a.out != nullptr, f32 = a.f32 != nullptr, vu = a.vu != nullptr;
+    if (a.streams == 0 || a.frames == 0)
+        return hipSuccess;
+    if (a.channels <= 2) {
+        // one 64-thread block per tile: 4 KiB when PCM or float is written, larger read-only
+        RunArgs b = a;
+        u32 tile_u = TILE_U;
+        if (!pcm && !f32) {
+            tile_u = a.channels == 1 ? TILE_U_VUONLY_MONO : TILE_U_VUONLY_STEREO;
+            const char *e = getenv("CMHIP_VU_TILE");
+            if (e) {
+                const int v = atoi(e);
+                if (v == 4 || v == 8 || v == 16)
+                    tile_u = (u32)v;
+            }
+        }
+        const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
+        b.chunks = (u32)((nvec + 64ull * tile_u - 1) / (64ull * tile_u));
+        if (b.chunks == 0)
+            b.chunks = 1;
+        if ((u64)b.chunks * a.streams >= (1ull << 31))
+            return hipErrorInvalidValue;
+        const u32 grid = a.streams * b.chunks;
+#define CMHIP_FAST(C, P, F, V, U)                                                  \
+    hipLaunchKernelGGL((k_run_fast<C, P, F, V, U>), dim3(grid), dim3(64), 0, st, b)
+#define CMHIP_FAST_C(C)                                                            \
+    do {                                                                           \
+        if (pcm && !f32 && vu) CMHIP_FAST(C, true, false, true, 4);                \
+        else if (!pcm && !f32 && vu && tile_u == 4) CMHIP_FAST(C, false, false, true, 4);   \
+        else if (!pcm && !f32 && vu && tile_u == 8) CMHIP_FAST(C, false, false, true, 8);   \
+        else if (!pcm && !f32 && vu) CMHIP_FAST(C, false, false, true, 16);        \
+        else if (pcm && !f32 && !vu) CMHIP_FAST(C, true, false, false, 4);         \
+        else if (pcm && f32 && vu) CMHIP_FAST(C, true, true, true, 4);             \
+        else if (!pcm && f32 && vu) CMHIP_FAST(C, false, true, true, 4);           \
+        else if (pcm && f32 && !vu) CMHIP_FAST(C, true, true, false, 4);           \
+        else if (!pcm && f32 && !vu) CMHIP_FAST(C, false, true, false, 4);         \
+    } while (0)
+        if (a.channels == 1)
+            CMHIP_FAST_C(1);
+        else
+            CMHIP_FAST_C(2);
+#undef CMHIP_FAST_C
+#undef CMHIP_FAST
+    } else if ((a.channels == 4 || a.channels == 8) && a.identity_maps) {
+        RunArgs b = a;
+        // tile size: read-only runs take 16 KiB tiles, the rest 8 KiB (tools/bench_generic.py);
+        // 16 channels run faster on k_run_rows below (5.6 against 4.7 TB/s)
+        const u32 wu = (!pcm && !f32) ? 16u : 8u;
+        const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
+        b.chunks = (u32)((nvec + 64ull * wu - 1) / (64ull * wu));
+        if (b.chunks == 0)
+            b.chunks = 1;
+        if ((u64)b.chunks * a.streams >= (1ull << 31))
+            return hipErrorInvalidValue;
+        const u32 grid = a.streams * b.chunks;
+#define CMHIP_WIDE(C, P, F, V)                                                     \
+    do {                                                                           \
+        if (wu == 16u)                                                             \
+            hipLaunchKernelGGL((k_run_wide<C, P, F, V, 16>), dim3(grid), dim3(64), 0, st, b); \
+        else                                                                       \
+            hipLaunchKernelGGL((k_run_wide<C, P, F, V, 8>), dim3(grid), dim3(64), 0, st, b);  \
+    } while (0)
+#define CMHIP_WIDE_C(C)                                                            \
+    do {                                                                           \
+        if (pcm && !f32 && vu) CMHIP_WIDE(C, true, false, true);                   \
+        else if (!pcm && !f32 && vu) CMHIP_WIDE(C, false, false, true);            \
+        else if (pcm && !f32 && !vu) CMHIP_WIDE(C, true, false, false);            \
+        else if (pcm && f32 && vu) CMHIP_WIDE(C, true, true, true);                \
+        else if (!pcm && f32 && vu) CMHIP_WIDE(C, false, true, true);              \
+        else if (pcm && f32 && !vu) CMHIP_WIDE(C, true, true, false);              \
+        else if (!pcm && f32 && !vu) CMHIP_WIDE(C, false, true, false);            \
+    } while (0)
+        if (a.channels == 4)
+            CMHIP_WIDE_C(4);
+        else
+            CMHIP_WIDE_C(8);
+#undef CMHIP_WIDE_C
+#undef CMHIP_WIDE
+    } else {
+        // any other channel count, or channel maps on more than two channels: rows of W vectors
+        // so that every lane position keeps its channel
+        RunArgs b = a;
+        u32 g = a.channels, e = 8;
+        while (e) {                              // gcd(C, 8)
+            const u32 t = g % e;
+            g = e;
+            e = t;
+        }
+        const u32 P = a.channels / g;
+        const u32 W = 64u - 64u % P;
+        // rows per tile (~1 KiB each); with 4 or 8 channels (here only when they carry channel
+        // maps) every lane adds to the same few LDS words at the end: bigger tiles, fewer merges
+        const u32 rpt = P == 1 ? 32u : (!pcm && !f32) ? 16u : 8u;
+        const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
+        const u64 rows = (nvec + W - 1) / W;
+        b.chunks = (u32)((rows + rpt - 1) / rpt);
+        if (b.chunks == 0)
+            b.chunks = 1;
+        if ((u64)b.chunks * a.streams >= (1ull << 31))
+            return hipErrorInvalidValue;
+        const u32 grid = a.streams * b.chunks;
+#define CMHIP_ROWS(P_, F_, V_)                                                                      \
+    do {                                                                                            \
+        if (a.identity_maps)                                                                        \
+            hipLaunchKernelGGL((k_run_rows<P_, F_, V_, false>), dim3(grid), dim3(64), 0, st, b, W, rpt); \
+        else                                                                                        \
+            hipLaunchKernelGGL((k_run_rows<P_, F_, V_, true>), dim3(grid), dim3(64), 0, st, b, W, rpt);  \
+    } while (0)
+        if (pcm && !f32 && vu) CMHIP_ROWS(true, false, true);
+        else if (!pcm && !f32 && vu) CMHIP_ROWS(false, false, true);
+        else if (pcm && !f32 && !vu) CMHIP_ROWS(true, false, false);
+        else if (pcm && f32 && vu) CMHIP_ROWS(true, true, true);
+        else if (!pcm && f32 && vu) CMHIP_ROWS(false, true, true);
+        else if (pcm && f32 && !vu) CMHIP_ROWS(true, true, false);
+        else if (!pcm && f32 && !vu) CMHIP_ROWS(false, true, false);
+#undef CMHIP_ROWS
+    }
+    return hipGetLastError();
+}
+
+}  // namespace cmhip

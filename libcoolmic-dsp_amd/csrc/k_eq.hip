@@ -1,0 +1,819 @@
+// k_eq.hip -- the pipelined equaliser kernel (BASELINE config 3) and its launcher.
+#include "cmhip_device.h"
+
+namespace cmhip {
+
+// ---------------------------------------------------------------------------
+// EQ path: int16 -> channel map -> gain -> x/32768.f -> NSEC biquads (Direct Form I with the
+// fmaf order the oracle fixes) -> float planes and/or int16 (+VU of the int16 result).
+
+// float -> int16 of the EQ result: round to nearest even, saturate, NaN -> 0 (oracle_f32_to_i16)
+__device__ __forceinline__ int f32_to_i16(float y)
+{
+    float v = y * 32768.0f;
+    if (v != v)
+        return 0;
+    v = __builtin_rintf(v);                           // v_rndne_f32: nearest even
+    v = v >= 32767.0f ? 32767.0f : v;
+    v = v <= -32768.0f ? -32768.0f : v;
+    return (int)v;
+}
+
+// ---------------------------------------------------------------------------
+// The pipelined EQ kernel (1..4 sections; config 3 is its mono, float-planes case).
+//
+// The recurrence allows no parallelism along time, so the per-sample work is cut in two:
+//
+//   feed-forward  f[t] = fma(b2, x[t-2], fma(b1, x[t-1], b0*x[t]))      no loop-carried dependence
+//   recurrence    y[t] = fma(-a1, y[t-1], fma(-a2, y[t-2], f[t]))       two dependent FMAs
+//
+// which is the oracle's Direct Form I in the same operation order.  A workgroup owns G
+// rows (a row = one channel of one stream) and walks them in 64-frame blocks, one
+// __syncthreads() per block, with waves of four roles that hand 64-frame rows to each other
+// through double-buffered LDS tiles:
+//
+//   T-in waves (lane = row x 8-frame chunk; time-parallel, G/8 of them):
+//     global load (two blocks ahead) -> gain -> float -> feed-forward of section 0 -> F_0
+//   T-ff waves (same lane shape, G/2 rows each in passes of 8 rows):
+//     Y_k-1 -> feed-forward of section k -> F_k               (k = 1 .. NSEC-1)
+//     x[t-1], x[t-2] of a chunk come from the neighbouring lane by DPP (row_shr:1), those
+//     of a block's first chunk from the last chunk of the previous step (row_shl:7).
+//   R waves (lane = section x row; 64/G sections side by side, sequential in time):
+//     F_k (loaded into registers a step ahead) -> the two dependent FMAs per sample -> Y_k
+//   S work: Y_last -> coalesced non-temporal global stores (float planes), and for an int16
+//     result / VU window the conversion and the window of it; dealt out over R and T-ff waves
+//     (float planes only) or done by S waves of their own -- see eq_role() below.
+//
+// Measured on MI355X (tools/ubench_chain.hip, ubench_lds*.hip): a wave alone issues one
+// VALU op per ~4.3 clk, a dependent one after ~8; ds_read_b128 costs a wave ~5-10 clk to
+// issue, ds_write_b128 ~24 (50 when four waves write at once).  So the only waves that are
+// long per step by themselves are the R waves (16 reads, 128 FMAs, 16 writes); everything
+// without a recurrence is spread over T lanes, where a 64-frame row costs 2 reads + 2 writes.
+// Rows are 68 floats (16-byte aligned, lane-per-row b128 access without bank conflicts).
+
+#ifndef CMHIP_EQ_RLAG
+#define CMHIP_EQ_RLAG 1           // R waves load the next row into registers a step ahead (0: same step)
+#endif
+#ifndef CMHIP_EQ_RSLOTS
+#define CMHIP_EQ_RSLOTS 1         // row slots (of 8) whose stores each R wave takes when the output is float planes only
+#endif
+#ifndef CMHIP_EQ_ABL
+#define CMHIP_EQ_ABL 0            // `make abl`: timing-only builds with one part of the pipeline cut out
+#endif
+
+// Channels: a "row" is one channel of one stream -- every channel runs its stream's filter
+// with state of its own -- and a workgroup takes G / C whole streams.  CH = 1: mono, the 16-byte
+// vector loads and packed stores of config 3; CH = 2: stereo, two vector loads per chunk and one
+// v_perm_b32 per sample pair pick the row's channel (through the stream's channel map); CH = 0:
+// any count, the T lanes gather their channel's samples with 16-bit loads.  For CH != 1 the S
+// lanes scatter the int16 result into the interleaved frames.
+//
+// Wave order.  Waves w, w+4 and w+8 of a workgroup share a SIMD, and a step lasts as long as
+// the most loaded SIMD needs (issue slots plus the time its waves are blocked on LDS writes):
+// per step an R wave costs ~1100 clk of that, a T-in wave (load, gain, section 0) ~600, a
+// T-ff wave (feed-forward of the later sections, 16 rows) ~850, the S wave ~600.  The order
+// below pairs them so that no SIMD carries much more than a quarter of the total.
+enum : u32 { EQ_R = 0x00, EQ_TIN = 0x10, EQ_TFF = 0x20, EQ_S = 0x30, EQ_TS = 0x40 };   // TS: T-ff and S in one wave
+
+// waves of a workgroup: float planes only (NSW == 1) -> the store work rides on the T-ff waves
+// (8 waves: two per SIMD, 256 VGPRs each); int16 / VU outputs (NSW == 4) -> S waves of their own
+template <int NSEC, int G, int NSW>
+constexpr u32 eq_waves()
+{
+    constexpr u32 nrw = (NSEC + 64 / G - 1) / (64 / G);
+    return NSW == 1 ? (NSEC > 1 ? nrw + G / 8 + 2 : nrw + G / 8 + 1) : nrw + G / 8 + (NSEC > 1 ? 2 : 0) + NSW;
+}
+
+template <int NRW, int NTF, int NSW>
+__device__ __forceinline__ u32 eq_role(u32 wave)
+{
+    if constexpr (NTF == 2 && NSW == 1) {
+        if constexpr (NRW == 2) {                // SIMDs: {R0 Tin0} {R1 Tin1} {TS0 Tin2} {TS1 Tin3}
+#if defined(CMHIP_EQ_ORDER) && CMHIP_EQ_ORDER == 1   // {R0 TS0} {R1 TS1} {Tin0 Tin2} {Tin1 Tin3}
+            constexpr unsigned char t[8] = {EQ_R | 0, EQ_R | 1, EQ_TIN | 0, EQ_TIN | 1, EQ_TS | 0, EQ_TS | 1,
+                                            EQ_TIN | 2, EQ_TIN | 3};
+#elif defined(CMHIP_EQ_ORDER) && CMHIP_EQ_ORDER == 2 // {R0 Tin0} {R1 TS0} {Tin1 TS1} {Tin2 Tin3}
+            constexpr unsigned char t[8] = {EQ_R | 0, EQ_R | 1, EQ_TIN | 1, EQ_TIN | 2, EQ_TIN | 0, EQ_TS | 0,
+                                            EQ_TS | 1, EQ_TIN | 3};
+#elif defined(CMHIP_EQ_ORDER) && CMHIP_EQ_ORDER == 3 // {R0 R1} {TS0 TS1} {Tin0 Tin1} {Tin2 Tin3}
+            constexpr unsigned char t[8] = {EQ_R | 0, EQ_TS | 0, EQ_TIN | 0, EQ_TIN | 2, EQ_R | 1, EQ_TS | 1,
+                                            EQ_TIN | 1, EQ_TIN | 3};
+#else
+            constexpr unsigned char t[8] = {EQ_R | 0, EQ_R | 1, EQ_TS | 0, EQ_TS | 1, EQ_TIN | 0, EQ_TIN | 1,
+                                            EQ_TIN | 2, EQ_TIN | 3};
+#endif
+            return t[wave];
+        } else {                                 // {R0 TS0} {Tin0 TS1} {Tin1 Tin3} {Tin2}
+            constexpr unsigned char t[7] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 1, EQ_TIN | 2, EQ_TS | 0, EQ_TS | 1,
+                                            EQ_TIN | 3};
+            return t[wave];
+        }
+    } else if constexpr (NTF == 2) {
+        if constexpr (NRW == 2) {                // {Tff1 Tin0 S0} {R0 Tin1 S1} {R1 Tin2 S2} {Tff0 Tin3 S3}
+            constexpr unsigned char t[12] = {EQ_TFF | 1, EQ_R | 0, EQ_R | 1, EQ_TFF | 0, EQ_TIN | 0, EQ_TIN | 1,
+                                             EQ_TIN | 2, EQ_TIN | 3, EQ_S | 0, EQ_S | 1, EQ_S | 2, EQ_S | 3};
+            return t[wave];
+        } else {
+            constexpr unsigned char t[11] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 2, EQ_TIN | 3, EQ_S | 0, EQ_TIN | 1,
+                                             EQ_TFF | 0, EQ_TFF | 1, EQ_S | 1, EQ_S | 2, EQ_S | 3};
+            return t[wave];
+        }
+    } else if constexpr (NSW == 1) {             // one section: no T-ff waves
+        constexpr unsigned char t[6] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 1, EQ_TIN | 2, EQ_S | 0, EQ_TIN | 3};
+        return t[wave];
+    } else {
+        constexpr unsigned char t[9] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 1, EQ_TIN | 2, EQ_S | 0, EQ_TIN | 3,
+                                        EQ_S | 1, EQ_S | 2, EQ_S | 3};
+        return t[wave];
+    }
+}
+
+template <int NSEC, int G, int NSW, int CH>
+__global__ __launch_bounds__((eq_waves<NSEC, G, NSW>() * 64))
+void k_eq_pipe(EqArgs a)
+{
+    constexpr bool MONO = CH == 1, STEREO = CH == 2;
+    static_assert(G == 32, "the wave order below is laid out for 32 rows per workgroup");
+    constexpr u32 EP_TB = 64;                     // frames per block
+    constexpr u32 EP_ROW = EP_TB + 4;             // floats per LDS row
+    constexpr u32 EP_TILE = G * EP_ROW;           // floats per buffer slot
+    constexpr u32 SPW = 64 / G;                   // sections per R wave
+    constexpr u32 NRW = (NSEC + SPW - 1) / SPW;   // R waves
+    constexpr u32 NTF = NSEC > 1 ? 2 : 0;         // T-ff waves: G / 2 rows each, in PASSES of 8 rows
+    constexpr u32 PASSES = 2;
+    constexpr u32 NBUF = 2 * NSEC;                // F_0, Y_0, F_1, Y_1, ...
+    constexpr u32 SPR = EP_TB / 4;                // store lanes per row (4 frames each)
+    constexpr u32 RPI = 64 / SPR;                 // rows per store instruction
+    constexpr int DPP_SHR1 = 0x111, DPP_SHL7 = 0x107;
+    // the register prefetch of the R waves needs 128 VGPRs for two rows: only where the workgroup
+    // has at most two waves per SIMD (256 VGPRs each); with S waves of their own it would spill
+    constexpr bool RLAG = CMHIP_EQ_RLAG && eq_waves<NSEC, G, NSW>() <= 8;
+    constexpr u32 HOP = RLAG ? 3 : 2;             // steps from F_k to F_k+1
+    extern __shared__ float lds[];                // NBUF buffers x 2 slots x EP_TILE floats, then G counts
+    u32 *nfr_lds = reinterpret_cast<u32 *>(lds + NBUF * 2 * EP_TILE);
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const u32 C = MONO ? 1u : STEREO ? 2u : a.channels;
+    const u32 SPG = G / C;                                // whole streams of this workgroup
+    const u32 s0 = blockIdx.x * SPG;
+    // row r of the workgroup: channel r % C of stream s0 + r / C
+    auto row_stream = [&](u32 r, u32 &ch) -> u32 {
+        const u32 q = MONO ? r : r / C;
+        ch = MONO ? 0u : r - q * C;
+        return q < SPG ? s0 + q : 0xffffffffu;            // rows past the last whole stream idle
+    };
+
+    const u32 role = eq_role<(int)NRW, (int)NTF, NSW>(wave);
+    const bool is_rec = (role & 0xf0u) == EQ_R;
+    const bool is_tin = (role & 0xf0u) == EQ_TIN;
+    const bool is_tff = (role & 0xf0u) == EQ_TFF || (role & 0xf0u) == EQ_TS;
+    // store work: the G / 4 row slots (four rows each) of Y_last are dealt out by role.  Float planes
+    // only, three or four sections: CMHIP_EQ_RSLOTS slots to each R wave, the rest to the T-ff waves
+    // (evens the SIMDs out); two sections: half to each T-ff wave; otherwise the S waves share them.
+    constexpr bool S_ON_R = NSW == 1 && NRW == 2 && NTF == 2;
+    constexpr u32 NSLOT = G / 4;
+    constexpr u32 RSL = CMHIP_EQ_RSLOTS, TSL = (NSLOT - 2 * RSL) / 2;    // slots of an R / a T-ff wave (S_ON_R)
+    constexpr u32 NSL = S_ON_R ? (RSL > TSL ? RSL : TSL) : (NSW == 1 && NTF == 2) ? NSLOT / 2 : NSLOT / NSW;
+    u32 s_first = 0, s_cnt = 0;                           // (NSL: most slots of a wave)
+    if (S_ON_R) {
+        if ((role & 0xf0u) == EQ_R) { s_first = RSL * (role & 15u); s_cnt = RSL; }
+        if ((role & 0xf0u) == EQ_TS) { s_first = 2u * RSL + TSL * (role & 15u); s_cnt = TSL; }
+    } else if ((role & 0xf0u) == EQ_S || (role & 0xf0u) == EQ_TS) {
+        s_first = NSL * (role & 15u);
+        s_cnt = NSL;
+    }
+    const bool is_store = s_cnt != 0;
+    const u32 tw = role & 15u;                            // T-in / T-ff wave index
+
+    // R lanes: section and stream row
+    const u32 sec = (role & 15u) * SPW + lane / G;
+    const bool has_sec = is_rec && sec < (u32)NSEC;
+    const u32 row = lane % G;
+    u32 my_ch;
+    const u32 sl = row_stream(row, my_ch);
+    const bool live = sl < a.streams;
+    const u32 sidx = live ? sl * C + my_ch : 0u;           // EqState index of this row
+    const u32 my_nfr = live ? (a.nframes ? a.nframes[sl] : a.frames) : 0u;
+    if (wave == 0 && lane < G)
+        nfr_lds[lane] = my_nfr;
+    u32 nmax = my_nfr;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1)
+        nmax = max(nmax, (u32)__shfl_xor((int)nmax, o, 64));
+    const u32 nblocks = (nmax + EP_TB - 1) / EP_TB;
+    const u32 nsteps = nblocks + HOP * NSEC;
+    __syncthreads();
+
+    // R lanes own y1, y2 of their section (EqState: x1 x2 y1 y2)
+    float d1 = 0, d2 = 0, h1 = 0, h2 = 0;
+    if (has_sec && live) {
+        const float *c = a.eq[sl].coef[sec];
+        const float *st = a.state[sidx].s[sec];
+        d1 = -c[3]; d2 = -c[4];
+        h1 = st[2]; h2 = st[3];
+    }
+
+    // T lanes: stream row l_r, frames l_t8 .. l_t8+7 of every block
+    const u32 l_r = 8u * tw + lane / 8u;
+    const u32 l_c = lane % 8u;
+    const u32 l_t8 = l_c * 8u;
+    u32 l_ch;
+    const u32 l_stream = row_stream(l_r, l_ch);
+    const u32 l_s = min(l_stream, a.streams - 1);
+    const bool l_live = is_tin && l_stream < a.streams;
+    const u32 l_sidx = l_s * C + l_ch;
+    u32 l_magic = 0, l_shift = 0, l_g2 = 0, l_n = 0, l_m = 0;
+    // feed-forward registers: b0 b1 b2 and x[t-1], x[t-2] before the next block.  A T-in lane
+    // uses [0][0] for section 0 of its row; a T-ff lane [p][k] for section k of the row of pass p.
+    float fc[PASSES][NSEC][3];
+    float sx1[PASSES][NSEC], sx2[PASSES][NSEC];
+#pragma unroll
+    for (u32 p = 0; p < PASSES; p++)
+#pragma unroll
+        for (int k = 0; k < NSEC; k++) {
+            fc[p][k][0] = fc[p][k][1] = fc[p][k][2] = 0.f;
+            sx1[p][k] = sx2[p][k] = 0.f;
+        }
+    if (is_tin) {
+        l_magic = a.param[l_s].magic;
+        l_shift = a.param[l_s].shift;
+        l_g2 = a.param[l_s].gain2[l_ch];
+        l_m = MONO ? 0u : a.param[l_s].chmap[l_ch];       // the input channel this row reads
+        l_n = nfr_lds[l_r];
+        if (l_live) {
+            // section 0 sees integer-valued samples (the 2^-15 of "x / 32768.f" is not applied
+            // by the conversion): it is folded into the coefficients instead, which is
+            // bit-identical because power-of-two scaling commutes with every rounding of the
+            // chain.  Its history is kept in the same unscaled form inside the kernel and
+            // converted at the EqState boundary.
+            const float *c = a.eq[l_s].coef[0];
+            const float *st = a.state[l_sidx].s[0];
+            fc[0][0][0] = c[0] * (1.0f / 32768.0f);
+            fc[0][0][1] = c[1] * (1.0f / 32768.0f);
+            fc[0][0][2] = c[2] * (1.0f / 32768.0f);
+            sx1[0][0] = st[0] * 32768.0f;
+            sx2[0][0] = st[1] * 32768.0f;
+        }
+    }
+    u32 f_r[PASSES];                                      // T-ff: row of pass p
+#pragma unroll
+    for (u32 p = 0; p < PASSES; p++) {
+        f_r[p] = (G / 2u) * tw + 8u * p + lane / 8u;
+        if (is_tff) {
+            u32 fch;
+            const u32 fs = row_stream(f_r[p], fch);
+            if (fs < a.streams) {
+#pragma unroll
+                for (int k = 1; k < NSEC; k++) {
+                    const float *c = a.eq[fs].coef[k];
+                    const float *st = a.state[fs * C + fch].s[k];
+                    fc[p][k][0] = c[0]; fc[p][k][1] = c[1]; fc[p][k][2] = c[2];
+                    sx1[p][k] = st[0]; sx2[p][k] = st[1];
+                }
+            }
+        }
+    }
+
+    // gain disabled (scale 0, or every gain equal to the scale) is stored as 1/1: x -> x
+    const bool gain_off = __all(l_g2 == 2u && l_shift == 0u);
+
+    // The T waves keep two blocks of PCM in flight: a block's HBM latency is hidden behind
+    // two pipeline steps.  The load is unconditional (address clamped into the stream's own
+    // row, which is a multiple of 8 samples long) and nothing else in a T wave touches
+    // global memory inside the loop, so the compiler can wait with vmcnt(1) for the older
+    // block instead of draining the queue; the stores have a wave of their own.
+    const int16_t *l_src = a.in + (u64)l_s * a.stride;
+    // (EQ batches have rows of whole 8-frame chunks, so a chunk with a valid frame is never clamped)
+    const u32 l_last = (u32)a.stride - (MONO ? 8u : STEREO ? 16u : 1u);
+    const u32 l_sel = l_m ? 0x07060302u : 0x05040100u;    // STEREO: which halves of two frames make a pair
+    struct Pcm { u32x4 a, b; };                           // a chunk in flight (b: second half, STEREO only)
+    auto fetch = [&](u32 b) -> Pcm {
+        const u32 f0 = b * EP_TB + l_t8;
+        Pcm r = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        if (CMHIP_EQ_ABL & 2) {
+            r.a = u32x4{f0, f0 * 3u, f0 * 5u, f0 * 7u};
+        } else if constexpr (MONO) {
+            r.a = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(l_src + min(f0, l_last)));
+        } else if constexpr (STEREO) {                    // 8 frames x (L, R): 32 bytes
+            const u32x4 *p = reinterpret_cast<const u32x4 *>(l_src + min(2u * f0, l_last));
+            r.a = __builtin_nontemporal_load(p);
+            r.b = __builtin_nontemporal_load(p + 1);
+        } else {
+            u32 h[8];                                     // frames f0..f0+7 of input channel l_m
+#pragma unroll
+            for (u32 k = 0; k < 8; k++)
+                h[k] = *reinterpret_cast<const uint16_t *>(l_src + min((f0 + k) * C + l_m, l_last));
+            r.a = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+        }
+        return r;
+    };
+    Pcm wa = {{0, 0, 0, 0}, {0, 0, 0, 0}}, wb = wa;       // blocks of even / odd steps
+    if (is_tin) {
+        wa = fetch(0);
+        wb = fetch(1);
+    }
+
+    // feed-forward half of section k on the 8 samples of this lane; the two samples before
+    // them come from the lane to the left, or (first chunk) from the end of the last block
+    auto feed_forward = [&](const u32 p, const int k, const float (&x)[8], float (&f)[8]) {
+        const float p1 = dpp_f32<DPP_SHR1>(x[7]), p2 = dpp_f32<DPP_SHR1>(x[6]);
+        const float q1 = dpp_f32<DPP_SHL7>(sx1[p][k]), q2 = dpp_f32<DPP_SHL7>(sx2[p][k]);
+        const float xm1 = l_c == 0 ? q1 : p1;
+        const float xm2 = l_c == 0 ? q2 : p2;
+        sx1[p][k] = x[7];
+        sx2[p][k] = x[6];
+        const float c0 = fc[p][k][0], c1 = fc[p][k][1], c2 = fc[p][k][2];
+        f[0] = __builtin_fmaf(c2, xm2, __builtin_fmaf(c1, xm1, c0 * x[0]));
+        f[1] = __builtin_fmaf(c2, xm1, __builtin_fmaf(c1, x[0], c0 * x[1]));
+#pragma unroll
+        for (int j = 2; j < 8; j++)
+            f[j] = __builtin_fmaf(c2, x[j - 2], __builtin_fmaf(c1, x[j - 1], c0 * x[j]));
+    };
+
+#ifdef CMHIP_EQ_STAMPS
+    u64 st_busy = 0, st_p[3] = {0, 0, 0};
+    const u64 st_begin = __builtin_readcyclecounter();
+#endif
+    // Schedule (HOP = 3): F_k of block b is written in step b+3k, loaded into the R lanes'
+    // registers in step b+3k+1 while they still work on block b-1, turned into Y_k in step
+    // b+3k+2, and the block leaves in step b+3*NSEC.  Every buffer is read one step after it
+    // was written, so two slots per buffer are enough (the third copy is in VGPRs).
+    auto rec_step = [&](float4 (&v)[EP_TB / 4], float4 (&nxt)[EP_TB / 4], const u32 step) {
+        if (!(CMHIP_EQ_ABL & 32)) {
+            const u32 first = HOP * sec + HOP - 1u;       // step in which block 0 is worked on
+            const u32 b = step - first;
+            if (RLAG) {                                   // next block's row: into registers now
+                const u32 bp = b + 1u;
+                if (has_sec && step + 1u >= first && bp < nblocks) {
+                    const float4 *in = reinterpret_cast<const float4 *>(
+                        lds + ((2u * sec) * 2u + (bp & 1u)) * EP_TILE + row * EP_ROW);
+#pragma unroll
+                    for (u32 t = 0; t < EP_TB / 4; t++)
+                        nxt[t] = in[t];
+                }
+            }
+            if (has_sec && step >= first && b < nblocks) {
+                float4 *out = reinterpret_cast<float4 *>(
+                    lds + ((2u * sec + 1u) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW);
+                if (!RLAG) {
+                    const float4 *in = reinterpret_cast<const float4 *>(
+                        lds + ((2u * sec) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW);
+#pragma unroll
+                    for (u32 t = 0; t < EP_TB / 4; t++)  // whole row first: 16 LDS reads in flight
+                        v[t] = in[t];
+                }
+                const u32 done = b * EP_TB;
+                const u32 cnt = my_nfr > done ? min(my_nfr - done, EP_TB) : 0u;
+                if (CMHIP_EQ_ABL & 4) {
+#pragma unroll
+                    for (u32 t = 0; t < EP_TB / 4; t++)
+                        out[t] = v[t];
+                } else if (__all(cnt == EP_TB)) {
+#pragma unroll
+                    for (u32 t = 0; t < EP_TB / 4; t++) {
+                        float4 y;
+                        y.x = __builtin_fmaf(d1, h1, __builtin_fmaf(d2, h2, v[t].x));
+                        y.y = __builtin_fmaf(d1, y.x, __builtin_fmaf(d2, h1, v[t].y));
+                        y.z = __builtin_fmaf(d1, y.y, __builtin_fmaf(d2, y.x, v[t].z));
+                        y.w = __builtin_fmaf(d1, y.z, __builtin_fmaf(d2, y.y, v[t].w));
+                        h2 = y.z;
+                        h1 = y.w;
+                        if (!(CMHIP_EQ_ABL & 8) || t == 0)
+                            out[t] = y;
+                    }
+                } else {
+                    // some stream ends inside this block: same arithmetic, but the history of a
+                    // lane moves only on its real samples (what lies beyond is never stored)
+#pragma unroll
+                    for (u32 t = 0; t < EP_TB / 4; t++) {
+                        const float xs[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+                        float rs[4];
+#pragma unroll
+                        for (u32 j = 0; j < 4; j++) {
+                            const float r = __builtin_fmaf(d1, h1, __builtin_fmaf(d2, h2, xs[j]));
+                            const bool real = 4u * t + j < cnt;
+                            h2 = real ? h1 : h2;
+                            h1 = real ? r : h1;
+                            rs[j] = r;
+                        }
+                        out[t] = make_float4(rs[0], rs[1], rs[2], rs[3]);
+                    }
+                }
+            }
+        }
+    };
+    float keep1 = 0.f, keep2 = 0.f;                       // section 0's new x1 / x2, if seen
+    bool has1 = false, has2 = false;
+    auto tin_step = [&](Pcm &wcur, const u32 step) {
+        if (!(CMHIP_EQ_ABL & 128)) {
+#ifdef CMHIP_EQ_STAMPS
+            const u64 st_tt = __builtin_readcyclecounter();
+#endif
+            // --- input block `step`: PCM -> gain -> float -> feed-forward of section 0 -> F_0
+            // (also in the drain steps at the end, where it works on zeros: keeping the load
+            // unconditional is what lets the wait above be counted)
+            if (!(CMHIP_EQ_ABL & 64)) {
+                const u32 b = step;
+                const u32 f0 = b * EP_TB + l_t8;
+                const bool have = f0 < l_n;               // beyond the end of the stream: zeros
+                u32 w[4] = {wcur.a.x, wcur.a.y, wcur.a.z, wcur.a.w};
+                if constexpr (STEREO) {                   // this row's channel of the eight frames
+                    w[0] = __builtin_amdgcn_perm(wcur.a.y, wcur.a.x, l_sel);
+                    w[1] = __builtin_amdgcn_perm(wcur.a.w, wcur.a.z, l_sel);
+                    w[2] = __builtin_amdgcn_perm(wcur.b.y, wcur.b.x, l_sel);
+                    w[3] = __builtin_amdgcn_perm(wcur.b.w, wcur.b.z, l_sel);
+                }
+#pragma unroll
+                for (u32 q = 0; q < 4; q++)
+                    w[q] = have ? w[q] : 0u;              // (a chunk the stream ends in keeps what
+                wcur = fetch(b + 2);                      // follows in the row: never stored)
+#ifdef CMHIP_EQ_STAMPS
+                u32 stw = w[0];
+                asm volatile("" : "+v"(stw));
+                st_p[0] += __builtin_readcyclecounter() - st_tt;          // PCM of this block has arrived
+#endif
+                // gain in integers (exact), then straight to float: the magnitude is converted,
+                // the sign bit of the sample is copied in, and one med3 is the int16 saturation
+                float x[8], f[8];
+                if (gain_off) {                           // no master gain on any row of this wave
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) {
+                        x[2 * q] = (float)(int)(int16_t)(w[q] & 0xffffu);
+                        x[2 * q + 1] = (float)((int)w[q] >> 16);
+                    }
+                } else {
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) {
+                        const u32 sg = pk_sign(w[q]);
+                        const u32 aw = pk_sub(w[q] ^ sg, sg);
+                        const u32 n0 = __umul24(aw & 0xffffu, l_g2);
+                        const u32 n1 = __umul24(aw >> 16, l_g2);
+                        const float m0 = (float)(__umulhi(n0, l_magic) >> l_shift);
+                        const float m1 = (float)(__umulhi(n1, l_magic) >> l_shift);
+                        const u32 b0 = (__builtin_bit_cast(u32, m0) & 0x7fffffffu) | ((w[q] << 16) & 0x80000000u);
+                        const u32 b1 = (__builtin_bit_cast(u32, m1) & 0x7fffffffu) | (w[q] & 0x80000000u);
+                        x[2 * q] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, b0), -32768.0f, 32767.0f);
+                        x[2 * q + 1] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, b1), -32768.0f, 32767.0f);
+                    }
+                }
+                // The last real samples of a stream are section 0's x1/x2 for the next launch
+                // (unscaled form here, see above); they pass through exactly one lane each and
+                // are written after the loop.
+                const u32 bf = b * EP_TB;
+                if (l_live && l_n > bf && l_n <= bf + EP_TB) {
+                    const u32 e1 = l_n - 1u - bf;                     // last sample, block relative
+                    if ((e1 >> 3) == l_c) {
+                        float val = x[0];
+#pragma unroll
+                        for (u32 j = 1; j < 8; j++)
+                            val = (e1 & 7u) == j ? x[j] : val;
+                        keep1 = val;
+                        has1 = true;
+                    }
+                    if (e1 >= 1u) {
+                        const u32 e2 = e1 - 1u;
+                        if ((e2 >> 3) == l_c) {
+                            float val = x[0];
+#pragma unroll
+                            for (u32 j = 1; j < 8; j++)
+                                val = (e2 & 7u) == j ? x[j] : val;
+                            keep2 = val;
+                            has2 = true;
+                        }
+                    } else if (l_c == 7u) {
+                        keep2 = sx1[0][0];                            // the sample before this block
+                        has2 = true;
+                    }
+                }
+#ifdef CMHIP_EQ_STAMPS
+                asm volatile("" : "+v"(x[7]));
+                st_p[1] += __builtin_readcyclecounter() - st_tt;          // converted
+#endif
+                feed_forward(0, 0, x, f);
+                float4 *dst = reinterpret_cast<float4 *>(lds + (b & 1u) * EP_TILE + l_r * EP_ROW + l_t8);
+                dst[0] = make_float4(f[0], f[1], f[2], f[3]);
+                dst[1] = make_float4(f[4], f[5], f[6], f[7]);
+#ifdef CMHIP_EQ_STAMPS
+                asm volatile("" ::: "memory");
+                st_p[2] += __builtin_readcyclecounter() - st_tt;          // F_0 handed to the LDS queue
+#endif
+            }
+        }
+    };
+    // T-ff waves: feed-forward of the later sections, Y_k-1 -> F_k, for G / 2 rows in PASSES of
+    // eight (each with the history registers of its own rows)
+    auto tff_step = [&](const u32 step) {
+        if (!(CMHIP_EQ_ABL & (128 | 16))) {
+            // reads first, then arithmetic: one LDS latency per step where the registers allow
+            // it (two waves per SIMD), one per pass otherwise
+            constexpr u32 PG = RLAG ? PASSES : 1;         // passes whose rows are loaded together
+#pragma unroll
+            for (u32 p0 = 0; p0 < PASSES; p0 += PG) {
+                float4 yin[PG][NSEC][2];
+#pragma unroll
+                for (int k = 1; k < NSEC; k++) {
+                    const u32 b = step - HOP * (u32)k;
+                    if (step >= HOP * (u32)k && b < nblocks) {
+#pragma unroll
+                        for (u32 p = 0; p < PG; p++) {
+                            const float4 *src = reinterpret_cast<const float4 *>(
+                                lds + ((2u * k - 1u) * 2u + (b & 1u)) * EP_TILE + f_r[p0 + p] * EP_ROW + l_t8);
+                            yin[p][k][0] = src[0];
+                            yin[p][k][1] = src[1];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 1; k < NSEC; k++) {
+                    const u32 b = step - HOP * (u32)k;
+                    if (step >= HOP * (u32)k && b < nblocks) {
+#pragma unroll
+                        for (u32 p = 0; p < PG; p++) {
+                            const float4 v0 = yin[p][k][0], v1 = yin[p][k][1];
+                            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                            float f[8];
+                            feed_forward(p0 + p, k, x, f);
+                            float4 *dst = reinterpret_cast<float4 *>(
+                                lds + ((2u * k) * 2u + (b & 1u)) * EP_TILE + f_r[p0 + p] * EP_ROW + l_t8);
+                            dst[0] = make_float4(f[0], f[1], f[2], f[3]);
+                            dst[1] = make_float4(f[4], f[5], f[6], f[7]);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    // S wave: per row slot i (rows RPI*i + lane/16) the VU window of the int16 result
+    static_assert(RPI == 4, "a row slot is four rows");
+    u64 vpw[NSL], vky[NSL], vbase[NSL];
+    u32 v_stream[NSL], v_ch[NSL];                         // stream (or none) and channel of the slot's row
+#pragma unroll
+    for (u32 i = 0; i < NSL; i++) {
+        vpw[i] = vky[i] = vbase[i] = 0;
+        const u32 r = RPI * (s_first + i) + lane / SPR;
+        v_stream[i] = row_stream(r, v_ch[i]);
+        if (v_stream[i] >= a.streams || i >= s_cnt)
+            v_stream[i] = 0xffffffffu;
+        if (is_store && a.vu && v_stream[i] != 0xffffffffu)
+            vbase[i] = a.vu[v_stream[i]].samples[a.parity];
+    }
+    auto s_step = [&](const u32 step) {
+        if (!(CMHIP_EQ_ABL & 1)) {
+            // --- the finished block of the last section leaves: 256 B (float) / 128 B (int16)
+            // per stream row and instruction, fire and forget (this wave never waits for
+            // global memory); the int16 form is what the VU meter sees
+            const u32 b = step - HOP * NSEC;
+            if (step >= HOP * NSEC && b < nblocks) {
+                const float *Y = lds + ((2u * NSEC - 1u) * 2u + (b & 1u)) * EP_TILE;
+                const u32 t4 = (lane % SPR) * 4u;
+                const u32 f0 = b * EP_TB + t4;
+                float4 vin[NSL];                              // every LDS read of the step up front:
+                u32 nin[NSL];                                 // one latency, not one per row slot
+#pragma unroll
+                for (u32 i = 0; i < NSL; i++) {
+                    const u32 r = min(RPI * (s_first + i) + lane / SPR, (u32)G - 1u);   // (slots past s_cnt are skipped below)
+                    nin[i] = nfr_lds[r];
+                    vin[i] = *reinterpret_cast<const float4 *>(Y + r * EP_ROW + t4);
+                }
+#pragma unroll
+                for (u32 i = 0; i < NSL; i++) {
+                    const u32 n = nin[i];
+                    const float4 v = vin[i];
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+                    const u32 vs_ = v_stream[i], vc_ = v_ch[i];
+                    if (vs_ == 0xffffffffu)
+                        continue;
+                    if (a.f32) {
+                        float *dstf = a.f32 + ((u64)vs_ * C + vc_) * a.plane + f0;
+                        if (f0 + 4u <= n) {
+                            typedef float f32x4 __attribute__((ext_vector_type(4)));
+                            const f32x4 vv = {v.x, v.y, v.z, v.w};
+                            __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(dstf));
+                        } else if (f0 < n) {
+                            for (u32 j = 0; j < n - f0; j++)
+                                dstf[j] = e[j];
+                        }
+                    }
+                    if (a.out || a.vu) {
+                        int q[4];
+#pragma unroll
+                        for (u32 j = 0; j < 4; j++)
+                            q[j] = f32_to_i16(e[j]);
+                        const bool whole = __all(f0 + 4u <= n);     // no stream ends inside these
+                        if (a.out) {
+                            if constexpr (MONO) {
+                                int16_t *d16 = a.out + (u64)vs_ * a.stride + f0;
+                                if (f0 + 4u <= n) {
+                                    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+                                    const u32x2 pk = {((u32)q[0] & 0xffffu) | ((u32)q[1] << 16),
+                                                      ((u32)q[2] & 0xffffu) | ((u32)q[3] << 16)};
+                                    __builtin_nontemporal_store(pk, reinterpret_cast<u32x2 *>(d16));
+                                } else if (f0 < n) {
+                                    for (u32 j = 0; j < n - f0; j++)
+                                        d16[j] = (int16_t)q[j];
+                                }
+                            } else {                      // interleaved result: this row's channel
+                                int16_t *d16 = a.out + (u64)vs_ * a.stride + (u64)f0 * C + vc_;
+#pragma unroll
+                                for (u32 j = 0; j < 4; j++)
+                                    if (f0 + j < n)
+                                        d16[j * C] = (int16_t)q[j];
+                            }
+                        }
+                        if (a.vu) {
+                            u32 am[4];
+#pragma unroll
+                            for (u32 j = 0; j < 4; j++) {
+                                am[j] = (u32)(q[j] < 0 ? -q[j] : q[j]);
+                                if (!whole)
+                                    am[j] = f0 + j < n ? am[j] : 0u;
+                            }
+#pragma unroll
+                            for (u32 j = 0; j < 4; j++)
+                                vpw[i] += (u64)am[j] * am[j];
+                            u32 m = am[0], jm = 0;                     // first of the largest
+#pragma unroll
+                            for (u32 j = 1; j < 4; j++) {
+                                const bool gt = am[j] > m;
+                                m = gt ? am[j] : m;
+                                jm = gt ? j : jm;
+                            }
+                            int qm = q[0];
+#pragma unroll
+                            for (u32 j = 1; j < 4; j++)
+                                qm = jm == j ? q[j] : qm;
+                            const u64 kk = make_key(m, vbase[i] + (u64)(f0 + jm) * C + vc_, qm < 0 ? 1u : 0u);
+                            vky[i] = kk > vky[i] ? kk : vky[i];
+                        }
+                    }
+                }
+            }
+        }
+    };
+#ifdef CMHIP_EQ_STAMPS
+#define EQ_STEP(call)                                                   \
+    do {                                                                \
+        const u64 st_t0 = __builtin_readcyclecounter();                 \
+        call;                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+        st_busy += __builtin_readcyclecounter() - st_t0;                \
+        __syncthreads();                                                \
+    } while (0)
+#else
+#define EQ_STEP(call) do { call; __syncthreads(); } while (0)
+#endif
+    // One loop per role (the role never changes, and a loop of its own lets the compiler
+    // count a T wave's outstanding loads); every wave passes the same number of barriers.
+    const u32 nst2 = (nsteps + 1u) & ~1u;                 // an odd tail step finds nothing to do
+    if (is_rec) {
+        float4 ra[EP_TB / 4], rb[EP_TB / 4];
+#pragma unroll
+        for (u32 t = 0; t < EP_TB / 4; t++)
+            ra[t] = rb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (S_ON_R) {                          // the recurrence first, then this wave's share of the stores
+            for (u32 step = 0; step < nst2; step += 2) {
+#if defined(CMHIP_EQ_V) && CMHIP_EQ_V == 1
+                EQ_STEP((s_step(step), rec_step(ra, rb, step)));
+                EQ_STEP((s_step(step + 1), rec_step(rb, ra, step + 1)));
+#else
+                EQ_STEP((rec_step(ra, rb, step), s_step(step)));
+                EQ_STEP((rec_step(rb, ra, step + 1), s_step(step + 1)));
+#endif
+            }
+        } else {
+            for (u32 step = 0; step < nst2; step += 2) {
+                EQ_STEP(rec_step(ra, rb, step));
+                EQ_STEP(rec_step(rb, ra, step + 1));
+            }
+        }
+    } else if (is_store) {
+        if (is_tff) {                                     // float planes only: T-ff and S in one wave
+            for (u32 step = 0; step < nst2; step++)
+                EQ_STEP((tff_step(step), s_step(step)));
+        } else {
+            for (u32 step = 0; step < nst2; step++)
+                EQ_STEP(s_step(step));
+        }
+        if (a.vu) {
+            // the 16 lanes of a row hold parts of its window; lane 0 of them is the row's only writer
+#pragma unroll
+            for (u32 i = 0; i < NSL; i++) {
+                u64 pw = vpw[i], ky = vky[i];
+#pragma unroll
+                for (int o = SPR / 2; o > 0; o >>= 1) {
+                    pw += (u64)__shfl_xor((long long)pw, o, 64);
+                    const u64 ok = (u64)__shfl_xor((long long)ky, o, 64);
+                    ky = ok > ky ? ok : ky;
+                }
+                const u32 r = RPI * (s_first + i) + lane / SPR;
+                if (lane % SPR == 0 && v_stream[i] != 0xffffffffu) {
+                    VuState *vs = a.vu + v_stream[i];
+                    if (v_ch[i] == 0)
+                        vs->samples[a.parity ^ 1u] = vbase[i] + (u64)nfr_lds[r] * C;
+                    vs->power[v_ch[i]] += pw;
+                    if (ky > vs->key[v_ch[i]])
+                        vs->key[v_ch[i]] = ky;
+                }
+            }
+        }
+    } else if (is_tff) {
+        for (u32 step = 0; step < nst2; step++)
+            EQ_STEP(tff_step(step));
+    } else {
+        for (u32 step = 0; step < nst2; step += 2) {
+            EQ_STEP(tin_step(wa, step));
+            EQ_STEP(tin_step(wb, step + 1));
+        }
+        if (has1)
+            a.state[l_sidx].s[0][0] = keep1 * (1.0f / 32768.0f);
+        if (has2)
+            a.state[l_sidx].s[0][1] = keep2 * (1.0f / 32768.0f);
+    }
+#undef EQ_STEP
+#ifdef CMHIP_EQ_STAMPS
+    if (blockIdx.x == 7 && lane == 0 && a.dbg) {     // per-role busy cycles (tools/eq_stamps.py)
+        a.dbg[2 * wave] = st_busy;
+        a.dbg[2 * wave + 1] = __builtin_readcyclecounter() - st_begin;
+        a.dbg[41 + wave] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_ID
+        a.dbg[40] = nsteps;
+        if (is_tin && tw < 2) {                       // two T-in waves: phases inside a step
+            for (int i = 0; i < 3; i++)
+                a.dbg[50 + 3 * tw + i] = st_p[i];
+        }
+        a.dbg[20 + wave] = role;
+    }
+#endif
+
+    // state for the next launch.  y1/y2 of section k are also the x1/x2 of section k+1
+    // (its input is this section's output); section 0's x1/x2 were written by the T lanes.
+    if (has_sec && live) {
+        float *st = a.state[sidx].s[sec];
+        st[2] = h1;
+        st[3] = h2;
+        if (sec + 1u < (u32)NSEC) {
+            float *sn = a.state[sidx].s[sec + 1u];
+            if (my_nfr >= 2u) {
+                sn[0] = h1;
+                sn[1] = h2;
+            } else if (my_nfr == 1u) {
+                sn[1] = sn[0];
+                sn[0] = h1;
+            }
+        }
+    }
+}
+
+template <int NSEC, int G>
+static constexpr size_t eq_pipe_lds_bytes()
+{
+    return ((size_t)(2 * NSEC) * 2 * G * (64 + 4)) * sizeof(float) + G * sizeof(u32);
+}
+
+template <int NSEC, int G, int NSW, int CH>
+static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
+{
+    constexpr size_t lds_bytes = eq_pipe_lds_bytes<NSEC, G>();
+    static_assert(lds_bytes <= 160 * 1024, "tiles of a workgroup must fit the LDS");
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G, NSW, CH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess)
+            return e;
+        configured = true;
+    }
+    const u32 spg = CH == 1 ? G : G / a.channels;         // whole streams per workgroup
+    hipLaunchKernelGGL((k_eq_pipe<NSEC, G, NSW, CH>), dim3((a.streams + spg - 1) / spg),
+                       dim3(eq_waves<NSEC, G, NSW>() * 64), lds_bytes, st, a);
+    return hipGetLastError();
+}
+
+// 32 rows per workgroup: all 256 CUs at 8192 mono streams, and what the LDS holds for four
+// sections (8 and 16 rows with several workgroups per CU measured the same or slower)
+template <int NSEC>
+static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st)
+{
+    // the int16 conversion and the VU window are per-sample work of the S waves: more of them
+    const bool heavy = a.out || a.vu;
+    if (a.channels == 1)
+        return heavy ? launch_eq_pipe<NSEC, 32, 4, 1>(a, st) : launch_eq_pipe<NSEC, 32, 1, 1>(a, st);
+    if (a.channels == 2 && a.stride >= 16 && a.stride % 16 == 0)
+        return heavy ? launch_eq_pipe<NSEC, 32, 4, 2>(a, st) : launch_eq_pipe<NSEC, 32, 1, 2>(a, st);
+    return heavy ? launch_eq_pipe<NSEC, 32, 4, 0>(a, st) : launch_eq_pipe<NSEC, 32, 1, 0>(a, st);
+}
+
+hipError_t launch_eq(const EqArgs &a, hipStream_t st)
+{
+    if (a.streams == 0 || a.frames == 0 || !(a.f32 || a.out || a.vu))
+        return hipSuccess;
+    if (a.channels == 0 || a.channels > MAX_CH)
+        return hipErrorInvalidValue;
+    switch (a.nsec) {                                     // (0 sections: the caller uses launch_run)
+    case 1: return launch_eq_pipe_g<1>(a, st);            // the pipelined kernel, whatever is asked
+    case 2: return launch_eq_pipe_g<2>(a, st);            // for (float planes, int16, VU of it)
+    case 3: return launch_eq_pipe_g<3>(a, st);
+    case 4: return launch_eq_pipe_g<4>(a, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace cmhip

@@ -1,0 +1,224 @@
+// k_misc.hip -- small kernels beside the path: synthetic inputs, the node-global VU partial,
+// plain HBM ceilings.
+#include "cmhip_device.h"
+
+namespace cmhip {
+
+// ---------------------------------------------------------------------------
+// Synthetic inputs, bit-identical to the host generators.
+
+__constant__ u32 c_lcg_a[32];
+__constant__ u32 c_lcg_c[32];
+
+__device__ __forceinline__ u32 lcg_skip(u32 state, u64 n)
+{
+    for (int i = 0; i < 32 && n; i++, n >>= 1)
+        if (n & 1)
+            state = state * c_lcg_a[i] + c_lcg_c[i];
+    return state;
+}
+
+__global__ __launch_bounds__(256) void k_generate(GenArgs g, int mode, u32 vec_per_stream)
+{
+    const u64 gid = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u32 s = (u32)(gid / vec_per_stream);
+    const u32 v = (u32)(gid - (u64)s * vec_per_stream);
+    if (s >= g.streams)
+        return;
+    const u64 gs = g.first_global + (u64)s * g.global_step;      // global stream id
+    const u32 nsamp = g.frames * g.channels;
+    int16_t *dst = g.dst + (u64)s * g.stride + (u64)v * 8;
+    int16_t val[8];
+    if (mode == 2) {
+        u32 st = lcg_skip(g.seed + (u32)gs, g.frame_offset * g.channels + (u64)v * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            st = st * 1664525u + 1013904223u;
+            val[j] = (int16_t)(st >> 16);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u64 f = g.frame_offset + ((u64)v * 8 + j) / g.channels;
+            val[j] = mode == 1 ? g.sine[(f + 7ull * gs) % 48ull] : (int16_t)0;
+        }
+    }
+    if (v * 8u + 8u <= nsamp) {
+        uint4 w;
+        w.x = (u32)(uint16_t)val[0] | ((u32)(uint16_t)val[1] << 16);
+        w.y = (u32)(uint16_t)val[2] | ((u32)(uint16_t)val[3] << 16);
+        w.z = (u32)(uint16_t)val[4] | ((u32)(uint16_t)val[5] << 16);
+        w.w = (u32)(uint16_t)val[6] | ((u32)(uint16_t)val[7] << 16);
+        *reinterpret_cast<uint4 *>(dst) = w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (v * 8u + (u32)j < nsamp)
+                dst[j] = val[j];
+    }
+}
+
+hipError_t launch_generate(const GenArgs &g, int mode, hipStream_t st)
+{
+    static bool tables = false;
+    if (!tables) {
+        u32 a[32], c[32];
+        u32 aa = 1664525u, cc = 1013904223u;
+        for (int i = 0; i < 32; i++) {
+            a[i] = aa;
+            c[i] = cc;
+            cc = cc * (aa + 1u);
+            aa = aa * aa;
+        }
+        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_lcg_a), a, sizeof(a));
+        if (e != hipSuccess)
+            return e;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(c_lcg_c), c, sizeof(c));
+        if (e != hipSuccess)
+            return e;
+        tables = true;
+    }
+    const u32 vps = (g.frames * g.channels + 7u) / 8u;
+    const u64 total = (u64)vps * g.streams;
+    if (total == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_generate, dim3((u32)((total + 255) / 256)), dim3(256), 0, st, g, mode, vps);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Node partial: one record for all streams of the batch.
+//   node key = |peak| << 46 | (2^29-1 - min(frame,2^29-1)) << 17 | (65535 - stream%65536) << 1 | neg
+
+__global__ __launch_bounds__(256) void k_node_partial(const VuState *vu, u32 streams, u32 channels,
+                                                      u32 parity, u64 first_global, u64 global_step,
+                                                      long long *dst)
+{
+    __shared__ u64 lsum[MAX_CH + 1];
+    __shared__ u64 lkey[MAX_CH + 1];
+    if (threadIdx.x <= MAX_CH) {
+        lsum[threadIdx.x] = 0;
+        lkey[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    u64 sum[MAX_CH + 1], key[MAX_CH + 1];
+#pragma unroll
+    for (u32 c = 0; c <= MAX_CH; c++) {
+        sum[c] = 0;
+        key[c] = 0;
+    }
+    for (u32 s = blockIdx.x * 256u + threadIdx.x; s < streams; s += gridDim.x * 256u) {
+        const u64 gs = first_global + (u64)s * global_step;
+        sum[MAX_CH] += vu[s].samples[parity] / channels;
+#pragma unroll
+        for (u32 c = 0; c < MAX_CH; c++) {
+            if (c < channels) {
+                sum[c] += vu[s].power[c];
+                const u64 k0 = vu[s].key[c];
+                if (k0) {
+                    const u64 mag = k0 >> KEY_ABS_SHIFT;
+                    const u64 idx = ~(k0 >> 1) & KEY_IDX_MASK;
+                    u64 fr = idx / channels;
+                    fr = fr > 0x1fffffffull ? 0x1fffffffull : fr;
+                    const u64 nk = (mag << 46) | ((0x1fffffffull - fr) << 17) |
+                                   ((65535ull - (gs & 65535ull)) << 1) | (k0 & 1ull);
+                    key[c] = nk > key[c] ? nk : key[c];
+                    key[MAX_CH] = nk > key[MAX_CH] ? nk : key[MAX_CH];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (u32 c = 0; c <= MAX_CH; c++) {
+        const u64 ws = wave_sum(sum[c]);
+        const u64 wk = wave_max(key[c]);
+        if ((threadIdx.x & 63u) == 0) {
+            if (ws)
+                atomicAdd(&lsum[c], ws);
+            if (wk)
+                atomicMax(&lkey[c], wk);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x <= MAX_CH) {
+        u64 *d = reinterpret_cast<u64 *>(dst);
+        if (lsum[threadIdx.x])
+            atomicAdd(&d[threadIdx.x], lsum[threadIdx.x]);
+        if (lkey[threadIdx.x])
+            atomicMax(&d[MAX_CH + 1 + threadIdx.x], lkey[threadIdx.x]);
+    }
+}
+
+hipError_t launch_node_partial(const VuState *vu, u32 streams, u32 channels, u32 parity,
+                               uint64_t first_global, uint64_t global_step, long long *dst,
+                               hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(dst, 0, sizeof(long long) * (2 * MAX_CH + 2), st);
+    if (e != hipSuccess)
+        return e;
+    u32 grid = (streams + 255) / 256;
+    if (grid > 256)
+        grid = 256;
+    hipLaunchKernelGGL(k_node_partial, dim3(grid), dim3(256), 0, st, vu, streams, channels,
+                       parity, first_global, global_step, dst);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Plain HBM ceilings over the same buffers: read-only sum, and copy.
+// Same access shape as k_run_fast -- one short-lived wave per 4 KiB tile, four
+// non-temporal 16-byte accesses per lane -- with no arithmetic, so the numbers are what
+// the memory system gives this pattern (the best of the shapes in tools/ubench_copy*.hip).
+
+__global__ __launch_bounds__(64) void k_ceiling_read(const u32x4 *src, u64 nvec, u64 *sink)
+{
+    const u64 v0 = (u64)blockIdx.x * TILE_VEC + threadIdx.x;
+    u32 acc = 0;
+#pragma unroll
+    for (u32 u = 0; u < TILE_U; u++) {
+        const u64 i = v0 + 64u * u;
+        if (i < nvec) {
+            const u32x4 w = __builtin_nontemporal_load(src + i);
+            acc += w.x ^ w.y ^ w.z ^ w.w;
+        }
+    }
+    if (acc == 0x9e3779b9u)          // practically never: keeps the loads alive
+        atomicAdd(sink, 1ull);
+}
+
+__global__ __launch_bounds__(64) void k_ceiling_copy(const u32x4 *src, u32x4 *dst, u64 nvec)
+{
+    const u64 v0 = (u64)blockIdx.x * TILE_VEC + threadIdx.x;
+    u32x4 w[TILE_U];
+#pragma unroll
+    for (u32 u = 0; u < TILE_U; u++) {
+        const u64 i = v0 + 64u * u;
+        if (i < nvec)
+            w[u] = __builtin_nontemporal_load(src + i);
+    }
+#pragma unroll
+    for (u32 u = 0; u < TILE_U; u++) {
+        const u64 i = v0 + 64u * u;
+        if (i < nvec)
+            __builtin_nontemporal_store(w[u], dst + i);
+    }
+}
+
+hipError_t launch_ceiling(int mode, const void *src, void *dst, size_t bytes, u64 *sink,
+                          hipStream_t st)
+{
+    const u64 nvec = bytes / 16;
+    const u64 tiles = (nvec + TILE_VEC - 1) / TILE_VEC;
+    if (tiles == 0 || tiles >= (1ull << 31))
+        return hipErrorInvalidValue;
+    if (mode == 0)
+        hipLaunchKernelGGL(k_ceiling_read, dim3((u32)tiles), dim3(64), 0, st,
+                           reinterpret_cast<const u32x4 *>(src), nvec, sink);
+    else
+        hipLaunchKernelGGL(k_ceiling_copy, dim3((u32)tiles), dim3(64), 0, st,
+                           reinterpret_cast<const u32x4 *>(src), reinterpret_cast<u32x4 *>(dst),
+                           nvec);
+    return hipGetLastError();
+}
+
+}  // namespace cmhip

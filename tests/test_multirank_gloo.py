@@ -28,7 +28,7 @@ def _stream_pcm(orc, gs):
 
 def _node_record(orc, streams):
     """what cmhip_batch_vu_node_partial writes for these global streams (see the key layout
-    in include/coolmic_hip.h and csrc/cmhip_kernels.hip:k_node_partial)"""
+    in include/coolmic_hip.h and csrc/k_misc.hip:k_node_partial)"""
     w = np.zeros(34, dtype=np.int64)
     for gs in streams:
         x = _stream_pcm(orc, gs).astype(np.int64).reshape(-1, C)
