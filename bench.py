@@ -70,15 +70,27 @@ def main():
                      "python -m torch.distributed.run --nproc-per-node %d ..." % (args.gpus, args.gpus))
         args.gpus = world
 
-    # torch is plumbing for the multi-rank run only (rendezvous, RCCL, the clock over ranks).  A
-    # single rank does not load it: torch brings its own HIP runtime (ROCm 7.0 inside the wheel),
-    # and under that runtime's default direct dispatch the submitting thread of this step loop was
-    # seen stalling for a kernel's length per step on busy hosts (0.7 ms per step instead of 0.37;
-    # DESIGN.md section 5).  With torch loaded, AMD_DIRECT_DISPATCH=0 avoids that (0.40 ms).
+    # torch is plumbing for the multi-rank run only (rendezvous, the barrier and the clock over
+    # ranks; RCCL for the one workload with an exchange step, config 5).  It brings its own HIP
+    # runtime (ROCm 7.0 inside the wheel), and under that runtime's default direct dispatch the
+    # submitting thread of this step loop was seen stalling for a kernel's length per step on
+    # busy hosts (0.7 ms per step instead of 0.37).  So:
+    #   * one rank: torch is not loaded at all;
+    #   * several ranks without a data-path collective (c2, c3, c4): the engine is loaded FIRST
+    #     and keeps the system HIP runtime, torch comes second and only runs gloo on the CPU for
+    #     the barrier and the max-over-ranks clock -- torch.cuda is never touched;
+    #   * config 5 (node-global VU over RCCL): torch first, with AMD_DIRECT_DISPATCH=0 unless the
+    #     environment says otherwise (0.40 ms per step).
     force_node = os.environ.get("COOLMIC_BENCH_FORCE_NODE") == "1"       # single-rank test of the reduce path
+    # Rehearsal knob for a 1-GPU box (never set by the driver): all ranks share device 0 and any
+    # GPU collective is replaced by gloo on host copies, so the N>1 code can run without N GPUs.
+    rehearsal = os.environ.get("COOLMIC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
+    gpu_torch = args.workload == "c5" and (world > 1 or force_node)    # torch.cuda is needed
     need_torch = world > 1 or force_node
     torch = dist = None
-    if need_torch:
+    if gpu_torch:
         os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
         import torch
         import torch.distributed as dist
@@ -89,22 +101,21 @@ def main():
 
     if cm.device_count() < 1:
         sys.exit("bench.py: no HIP device; this path has no CPU fallback")
-    # Rehearsal knobs for a 1-GPU box (never set by the driver): all ranks share one device
-    # and the process group runs over gloo, so the N>1 code path can be exercised without N GPUs.
-    rehearsal = os.environ.get("COOLMIC_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local_rank = 0
-    if need_torch:
-        torch.cuda.set_device(local_rank)
+    if need_torch and not gpu_torch:
+        import torch
+        import torch.distributed as dist
     if need_torch:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29599")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
+        if gpu_torch and not rehearsal:
+            torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
-    coll_device = "cpu" if rehearsal else "cuda"
+        else:
+            if gpu_torch:
+                torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    coll_device = "cuda" if gpu_torch and not rehearsal else "cpu"
 
     S, Cn, T, bps, desc = WORKLOADS[args.workload]
     if args.frames:
@@ -171,7 +182,7 @@ def main():
 
     def device_sync():
         cm.device_synchronize(local_rank)       # hipDeviceSynchronize: every stream of this rank's GPU
-        if need_torch:
+        if gpu_torch:
             torch.cuda.synchronize()
 
     def barrier():
