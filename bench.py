@@ -47,8 +47,8 @@ WORKLOADS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)     # 100 x 0.37 ms: long enough to average host noise
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="override frames per launch")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
