@@ -700,7 +700,9 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
         const u32 W = 64u - 64u % P;
         // rows per tile (~1 KiB each); with 4 or 8 channels (here only when they carry channel
         // maps) every lane adds to the same few LDS words at the end: bigger tiles, fewer merges
-        const u32 rpt = P == 1 ? 32u : (!pcm && !f32) ? 16u : 8u;
+        u32 rpt = P == 1 ? 32u : (!pcm && !f32) ? 16u : 8u;
+        if (const char *e = getenv("CMHIP_ROWS_RPT"))          // tuning knob (tools/bench_generic.py)
+            rpt = (u32)atoi(e) ? (u32)atoi(e) : rpt;
         const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
         const u64 rows = (nvec + W - 1) / W;
         b.chunks = (u32)((rows + rpt - 1) / rpt);
