@@ -422,13 +422,18 @@ __global__ __launch_bounds__(64) void k_run_wide(RunArgs a)
 // lies in the same row: the raw row goes through LDS and every position gathers its source
 // with a 16-bit read at a per-lane constant offset.
 
-template <bool WRITE_PCM, bool WRITE_F32, bool DO_VU, bool MAP>
+// STAGE: planar floats go through LDS so that every plane leaves in whole runs (any count but 16,
+// where lanes of equal parity already hold consecutive frames of the same eight channels).
+template <bool WRITE_PCM, bool WRITE_F32, bool DO_VU, bool MAP, bool STAGE>
 __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_tile)
 {
     constexpr u32 UR = 4;                        // rows in flight
     __shared__ u64 lsum[MAX_CH];
     __shared__ u64 lkey[MAX_CH];
     __shared__ u32x4 raw[MAP ? UR * 64 : 1];     // the rows as loaded (MAP only)
+    // planar float output: the UR rows of a step, plane-major, so that every plane leaves in
+    // whole 16-byte stores of consecutive frames (UR * 8 * 64 floats at most)
+    __shared__ __attribute__((aligned(16))) float fstage[WRITE_F32 && STAGE ? UR * 8 * 64 : 4];
     const u32 lane = threadIdx.x;
     const u32 s = blockIdx.x / a.chunks;
     const u32 k = blockIdx.x - s * a.chunks;
@@ -565,16 +570,49 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
                 }
             }
             if constexpr (WRITE_F32) {
-                const u32 cnt = full[u] ? 8u : (tail[u] ? ntail : 0u);
-                const u32 fr = row * FW + lane_fr;
+                if constexpr (!STAGE) {
+                    // 16 channels: lanes of equal parity hold consecutive frames of the same eight
+                    // channels, so these stores are already runs of a plane
+                    const u32 cnt = full[u] ? 8u : (tail[u] ? ntail : 0u);
+                    const u32 fr = row * FW + lane_fr;
 #pragma unroll
-                for (u32 j = 0; j < 8; j++) {
-                    if (j < cnt) {
+                    for (u32 j = 0; j < 8; j++) {
+                        if (j < cnt) {
+                            const int q = (int)(short)((o[j >> 1] >> (16u * (j & 1u))) & 0xffffu);
+                            f32s[(u64)ch[j] * a.plane + fr + df[j]] = q * (1.0f / 32768.0f);
+                        }
+                    }
+                } else if (active) {
+                    // this lane's eight samples to [channel][frame of the UR-row step]
+#pragma unroll
+                    for (u32 j = 0; j < 8; j++) {
                         const int q = (int)(short)((o[j >> 1] >> (16u * (j & 1u))) & 0xffffu);
-                        f32s[(u64)ch[j] * a.plane + fr + df[j]] = q * (1.0f / 32768.0f);
+                        fstage[ch[j] * (UR * FW) + u * FW + lane_fr + df[j]] = q * (1.0f / 32768.0f);
                     }
                 }
             }
+        }
+        if constexpr (WRITE_F32 && STAGE) {
+            // every plane's UR*FW consecutive frames of this step leave as 16-byte stores
+            __syncthreads();
+            const u32 fbase = (row0 + r0) * FW;          // first frame of the step (a multiple of 4)
+            const u32 fcnt = UR * FW;                     // frames of the step
+            for (u32 c = 0; c < C; c++) {
+                float *plane_dst = f32s + (u64)c * a.plane + fbase;
+                for (u32 i4 = lane * 4u; i4 < fcnt; i4 += 256u) {
+                    const float4 v4 = *reinterpret_cast<const float4 *>(&fstage[c * fcnt + i4]);
+                    if (fbase + i4 + 4u <= nfr) {
+                        typedef float f32x4 __attribute__((ext_vector_type(4)));
+                        const f32x4 vv = {v4.x, v4.y, v4.z, v4.w};
+                        __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(plane_dst + i4));
+                    } else if (fbase + i4 < nfr) {
+                        const float e[4] = {v4.x, v4.y, v4.z, v4.w};
+                        for (u32 k2 = 0; fbase + i4 + k2 < nfr; k2++)
+                            plane_dst[i4 + k2] = e[k2];
+                    }
+                }
+            }
+            __syncthreads();                              // before the next step overwrites the stage
         }
     }
 
@@ -651,7 +689,10 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
             CMHIP_FAST_C(2);
 #undef CMHIP_FAST_C
 #undef CMHIP_FAST
-    } else if ((a.channels == 4 || a.channels == 8) && a.identity_maps) {
+    } else if ((a.channels == 4 || a.channels == 8) && a.identity_maps &&
+               !(a.channels == 4 && f32 && !getenv("CMHIP_WIDE4_F32"))) {
+        // (4-channel float planes: k_run_wide writes every other float of a line per store;
+        // k_run_rows stages the planes through LDS and runs 25 % faster there)
         RunArgs b = a;
         // tile size: read-only runs take 16 KiB tiles, the rest 8 KiB (tools/bench_generic.py);
         // 16 channels run faster on k_run_rows below (5.6 against 4.7 TB/s)
@@ -713,10 +754,15 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
         const u32 grid = a.streams * b.chunks;
 #define CMHIP_ROWS(P_, F_, V_)                                                                      \
     do {                                                                                            \
-        if (a.identity_maps)                                                                        \
-            hipLaunchKernelGGL((k_run_rows<P_, F_, V_, false>), dim3(grid), dim3(64), 0, st, b, W, rpt); \
+        constexpr bool S_ = F_;                        /* staged float planes unless 16 channels */ \
+        if (a.identity_maps && (!F_ || a.channels != 16))                                           \
+            hipLaunchKernelGGL((k_run_rows<P_, F_, V_, false, S_>), dim3(grid), dim3(64), 0, st, b, W, rpt); \
+        else if (a.identity_maps)                                                                   \
+            hipLaunchKernelGGL((k_run_rows<P_, F_, V_, false, false>), dim3(grid), dim3(64), 0, st, b, W, rpt); \
+        else if (!F_ || a.channels != 16)                                                           \
+            hipLaunchKernelGGL((k_run_rows<P_, F_, V_, true, S_>), dim3(grid), dim3(64), 0, st, b, W, rpt);  \
         else                                                                                        \
-            hipLaunchKernelGGL((k_run_rows<P_, F_, V_, true>), dim3(grid), dim3(64), 0, st, b, W, rpt);  \
+            hipLaunchKernelGGL((k_run_rows<P_, F_, V_, true, false>), dim3(grid), dim3(64), 0, st, b, W, rpt);  \
     } while (0)
         if (pcm && !f32 && vu) CMHIP_ROWS(true, false, true);
         else if (!pcm && !f32 && vu) CMHIP_ROWS(false, false, true);
