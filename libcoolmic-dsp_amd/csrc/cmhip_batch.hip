@@ -933,6 +933,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.streams = b->d.streams;
         a.channels = b->d.channels;
         a.nsec = b->nsec;
+        a.whole_streams = (b->d_out == b->d_in && !b->all_identity) ? 1u : 0u;
         a.parity = b->parity;
         a.dbg = b->d_dbg;
         a.stride = b->stride;

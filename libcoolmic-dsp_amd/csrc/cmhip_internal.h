@@ -82,6 +82,7 @@ struct EqArgs {
     uint32_t       streams;
     uint32_t       channels;       // every channel of a stream runs the stream's filter, with state of its own
     uint32_t       nsec;           // biquad sections, same for every stream of the batch
+    uint32_t       whole_streams;  // keep the channels of a stream in one workgroup (in place + channel maps)
     uint32_t       parity;
     uint64_t       stride;
     uint64_t       plane;

@@ -153,13 +153,19 @@ void k_eq_pipe(EqArgs a)
     u32 *nfr_lds = reinterpret_cast<u32 *>(lds + NBUF * 2 * EP_TILE);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const u32 C = MONO ? 1u : STEREO ? 2u : a.channels;
-    const u32 SPG = G / C;                                // whole streams of this workgroup
-    const u32 s0 = blockIdx.x * SPG;
-    // row r of the workgroup: channel r % C of stream s0 + r / C
+    // Rows are numbered stream * C + channel over the whole batch and a workgroup takes G
+    // consecutive ones (rows are independent, so a stream's channels may sit in two workgroups:
+    // no idle rows, and e.g. 1365 x 6 channels are 256 workgroups, not 273).
+    // (In place with channel maps a row may read what another row of its stream writes: then a
+    // stream's rows must stay in one workgroup, where the barriers order them -- whole_streams.)
+    const u32 SPG = G / C;
+    const u32 row0_global = a.whole_streams ? blockIdx.x * SPG * C : blockIdx.x * G;
+    const u32 rows_here = a.whole_streams ? SPG * C : (u32)G;
     auto row_stream = [&](u32 r, u32 &ch) -> u32 {
-        const u32 q = MONO ? r : r / C;
-        ch = MONO ? 0u : r - q * C;
-        return q < SPG ? s0 + q : 0xffffffffu;            // rows past the last whole stream idle
+        const u32 gr = row0_global + r;
+        const u32 q = MONO ? gr : STEREO ? gr >> 1 : gr / C;
+        ch = MONO ? 0u : gr - q * C;
+        return r < rows_here ? q : 0xffffffffu;           // (q >= streams: past the end of the batch)
     };
 
     const u32 role = eq_role<(int)NRW, (int)NTF, NSW>(wave);
@@ -781,8 +787,10 @@ static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
             return e;
         configured = true;
     }
-    const u32 spg = CH == 1 ? G : G / a.channels;         // whole streams per workgroup
-    hipLaunchKernelGGL((k_eq_pipe<NSEC, G, NSW, CH>), dim3((a.streams + spg - 1) / spg),
+    const u64 rows = (u64)a.streams * (CH == 1 ? 1u : a.channels);      // one row per stream and channel
+    const u32 spg = CH == 1 ? G : G / a.channels;
+    const u32 grid = a.whole_streams ? (a.streams + spg - 1) / spg : (u32)((rows + G - 1) / G);
+    hipLaunchKernelGGL((k_eq_pipe<NSEC, G, NSW, CH>), dim3(grid),
                        dim3(eq_waves<NSEC, G, NSW>() * 64), lds_bytes, st, a);
     return hipGetLastError();
 }
