@@ -617,6 +617,26 @@ void k_eq_pipe(EqArgs a)
                                     for (u32 j = 0; j < n - f0; j++)
                                         d16[j] = (int16_t)q[j];
                                 }
+                            } else if constexpr (STEREO) {
+                                // The two rows of a stream are 16 lanes apart: swap halves with the
+                                // partner (v_permlane16_swap) so that the left row's lanes hold
+                                // frames f0, f0+1 of both channels and the right row's lanes frames
+                                // f0+2, f0+3 -- whole interleaved frames, 8 bytes per lane.
+                                const u32 p01 = ((u32)q[0] & 0xffffu) | ((u32)q[1] << 16);
+                                const u32 p23 = ((u32)q[2] & 0xffffu) | ((u32)q[3] << 16);
+                                typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+                                const u32x2 sw2 = __builtin_amdgcn_permlane16_swap(p01, p23, false, false);
+                                const u32 left = sw2.x, right = sw2.y;   // this frame pair: channel 0, channel 1
+                                const u32 d0 = __builtin_amdgcn_perm(right, left, 0x05040100u);
+                                const u32 d1 = __builtin_amdgcn_perm(right, left, 0x07060302u);
+                                const u32 ff = f0 + 2u * vc_;            // first of this lane's two frames
+                                u32 *d32 = reinterpret_cast<u32 *>(a.out + (u64)vs_ * a.stride) + ff;
+                                if (ff + 2u <= n) {
+                                    const u32x2 pk = {d0, d1};
+                                    __builtin_nontemporal_store(pk, reinterpret_cast<u32x2 *>(d32));
+                                } else if (ff < n) {
+                                    d32[0] = d0;
+                                }
                             } else {                      // interleaved result: this row's channel
                                 int16_t *d16 = a.out + (u64)vs_ * a.stride + (u64)f0 * C + vc_;
 #pragma unroll
