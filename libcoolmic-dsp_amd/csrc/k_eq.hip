@@ -551,10 +551,12 @@ void k_eq_pipe(EqArgs a)
     // S wave: per row slot i (rows RPI*i + lane/16) the VU window of the int16 result
     static_assert(RPI == 4, "a row slot is four rows");
     u64 vpw[NSL], vky[NSL], vbase[NSL];
+    u32 vmag[NSL], vidx[NSL];                             // running peak: magnitude, frame << 1 | negative
     u32 v_stream[NSL], v_ch[NSL];                         // stream (or none) and channel of the slot's row
 #pragma unroll
     for (u32 i = 0; i < NSL; i++) {
         vpw[i] = vky[i] = vbase[i] = 0;
+        vmag[i] = vidx[i] = 0;
         const u32 r = RPI * (s_first + i) + lane / SPR;
         v_stream[i] = row_stream(r, v_ch[i]);
         if (v_stream[i] >= a.streams || i >= s_cnt)
@@ -600,10 +602,16 @@ void k_eq_pipe(EqArgs a)
                         }
                     }
                     if (a.out || a.vu) {
+                        // float -> int16 as oracle_f32_to_i16: y * 32768, round to nearest even, then the
+                        // hardware's saturating conversions do the rest (v_cvt_i32_f32: NaN -> 0, out of
+                        // range -> INT_MIN / INT_MAX; the packing below saturates to int16)
                         int q[4];
 #pragma unroll
-                        for (u32 j = 0; j < 4; j++)
-                            q[j] = f32_to_i16(e[j]);
+                        for (u32 j = 0; j < 4; j++) {
+                            const float r = __builtin_rintf(e[j] * 32768.0f);
+                            asm("v_cvt_i32_f32 %0, %1" : "=v"(q[j]) : "v"(r));
+                            q[j] = q[j] > 32767 ? 32767 : (q[j] < -32768 ? -32768 : q[j]);
+                        }
                         const bool whole = __all(f0 + 4u <= n);     // no stream ends inside these
                         if (a.out) {
                             if constexpr (MONO) {
@@ -646,29 +654,19 @@ void k_eq_pipe(EqArgs a)
                             }
                         }
                         if (a.vu) {
-                            u32 am[4];
+                            // running peak of the lane's samples of this row: they come in time order,
+                            // so "strictly greater" keeps the first of equals; the 64-bit key is built
+                            // once, after the loop
 #pragma unroll
                             for (u32 j = 0; j < 4; j++) {
-                                am[j] = (u32)(q[j] < 0 ? -q[j] : q[j]);
+                                u32 am = (u32)(q[j] < 0 ? -q[j] : q[j]);
                                 if (!whole)
-                                    am[j] = f0 + j < n ? am[j] : 0u;
+                                    am = f0 + j < n ? am : 0u;
+                                vpw[i] += (u64)am * am;
+                                const bool gt = am > vmag[i];
+                                vmag[i] = gt ? am : vmag[i];
+                                vidx[i] = gt ? ((f0 + j) << 1) | ((u32)q[j] >> 31) : vidx[i];
                             }
-#pragma unroll
-                            for (u32 j = 0; j < 4; j++)
-                                vpw[i] += (u64)am[j] * am[j];
-                            u32 m = am[0], jm = 0;                     // first of the largest
-#pragma unroll
-                            for (u32 j = 1; j < 4; j++) {
-                                const bool gt = am[j] > m;
-                                m = gt ? am[j] : m;
-                                jm = gt ? j : jm;
-                            }
-                            int qm = q[0];
-#pragma unroll
-                            for (u32 j = 1; j < 4; j++)
-                                qm = jm == j ? q[j] : qm;
-                            const u64 kk = make_key(m, vbase[i] + (u64)(f0 + jm) * C + vc_, qm < 0 ? 1u : 0u);
-                            vky[i] = kk > vky[i] ? kk : vky[i];
                         }
                     }
                 }
@@ -723,6 +721,7 @@ void k_eq_pipe(EqArgs a)
             // the 16 lanes of a row hold parts of its window; lane 0 of them is the row's only writer
 #pragma unroll
             for (u32 i = 0; i < NSL; i++) {
+                vky[i] = make_key(vmag[i], vbase[i] + (u64)(vidx[i] >> 1) * C + v_ch[i], vidx[i] & 1u);
                 u64 pw = vpw[i], ky = vky[i];
 #pragma unroll
                 for (int o = SPR / 2; o > 0; o >>= 1) {

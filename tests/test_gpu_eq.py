@@ -258,3 +258,37 @@ def test_eq_on_multichannel_streams(gpu, oracle, C):
                 if rc_o == 0:
                     assert r_g.as_dict() == of.vu_result_dict(r_o), (C, flags, s)
         b.close()
+
+
+def test_eq_non_finite_results_saturate_like_the_oracle(gpu, oracle):
+    """a filter that overflows: +-inf and NaN in the float result; the int16 result saturates
+    and takes 0 for NaN exactly as oracle_f32_to_i16 says (the S waves use the hardware's
+    saturating conversions for this), and the VU window follows the int16 result"""
+    cm = gpu
+    rng = np.random.default_rng(99)
+    S, T = 40, 500
+    coef = np.array([3.0e38, -3.0e38, 3.0e38, 0.25, 0.5,        # overflows within a few samples
+                     1.0, 0.0, 0.0, 0.0, 0.0], dtype=np.float32)
+    b = cm.Batch(S, 1, T, flags=cm.EQ | cm.OUT_F32 | cm.OUT_PCM | cm.VU)
+    assert b.set_eq(-1, coef) == 0
+    xs = [rng.integers(-32768, 32768, T).astype(np.int16) for _ in range(S)]
+    for s in range(S):
+        b.upload(s, xs[s])
+    b.run(T)
+    saw_nan = saw_inf = False
+    for s in range(S):
+        (wf, wi), = _oracle_eq(oracle, coef, 2, None, [xs[s]])
+        gf, gi = b.download_f32(s, 0, T), b.download(s, T)
+        saw_nan |= bool(np.isnan(wf).any())
+        saw_inf |= bool(np.isinf(wf).any())
+        assert np.array_equal(np.isnan(gf), np.isnan(wf)), s
+        fin = ~np.isnan(wf)
+        assert np.array_equal(gf[fin].view(np.uint32), wf[fin].view(np.uint32)), s
+        assert np.array_equal(gi, wi), s
+        v = oracle.vu_new(1)
+        oracle.vu_accumulate(v, wi)
+        rc_o, r_o = oracle.vu_result(v)
+        rc_g, r_g = b.vu_result(s)
+        assert rc_g == rc_o == 0 and r_g.as_dict() == of.vu_result_dict(r_o), s
+    assert saw_nan and saw_inf
+    b.close()
