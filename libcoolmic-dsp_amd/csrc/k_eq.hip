@@ -717,29 +717,6 @@ void k_eq_pipe(EqArgs a)
             for (u32 step = 0; step < nst2; step++)
                 EQ_STEP(s_step(step));
         }
-        if (a.vu) {
-            // the 16 lanes of a row hold parts of its window; lane 0 of them is the row's only writer
-#pragma unroll
-            for (u32 i = 0; i < NSL; i++) {
-                vky[i] = make_key(vmag[i], vbase[i] + (u64)(vidx[i] >> 1) * C + v_ch[i], vidx[i] & 1u);
-                u64 pw = vpw[i], ky = vky[i];
-#pragma unroll
-                for (int o = SPR / 2; o > 0; o >>= 1) {
-                    pw += (u64)__shfl_xor((long long)pw, o, 64);
-                    const u64 ok = (u64)__shfl_xor((long long)ky, o, 64);
-                    ky = ok > ky ? ok : ky;
-                }
-                const u32 r = RPI * (s_first + i) + lane / SPR;
-                if (lane % SPR == 0 && v_stream[i] != 0xffffffffu) {
-                    VuState *vs = a.vu + v_stream[i];
-                    if (v_ch[i] == 0)
-                        vs->samples[a.parity ^ 1u] = vbase[i] + (u64)nfr_lds[r] * C;
-                    vs->power[v_ch[i]] += pw;
-                    if (ky > vs->key[v_ch[i]])
-                        vs->key[v_ch[i]] = ky;
-                }
-            }
-        }
     } else if (is_tff) {
         for (u32 step = 0; step < nst2; step++)
             EQ_STEP(tff_step(step));
@@ -754,6 +731,31 @@ void k_eq_pipe(EqArgs a)
             a.state[l_sidx].s[0][1] = keep2 * (1.0f / 32768.0f);
     }
 #undef EQ_STEP
+
+    // VU windows of the int16 result: every wave that did store work holds parts of them
+    if (is_store && a.vu) {
+        // the 16 lanes of a row hold parts of its window; lane 0 of them is the row's only writer
+#pragma unroll
+        for (u32 i = 0; i < NSL; i++) {
+            vky[i] = make_key(vmag[i], vbase[i] + (u64)(vidx[i] >> 1) * C + v_ch[i], vidx[i] & 1u);
+            u64 pw = vpw[i], ky = vky[i];
+#pragma unroll
+            for (int o = SPR / 2; o > 0; o >>= 1) {
+                pw += (u64)__shfl_xor((long long)pw, o, 64);
+                const u64 ok = (u64)__shfl_xor((long long)ky, o, 64);
+                ky = ok > ky ? ok : ky;
+            }
+            const u32 r = RPI * (s_first + i) + lane / SPR;
+            if (lane % SPR == 0 && v_stream[i] != 0xffffffffu) {
+                VuState *vs = a.vu + v_stream[i];
+                if (v_ch[i] == 0)
+                    vs->samples[a.parity ^ 1u] = vbase[i] + (u64)nfr_lds[r] * C;
+                vs->power[v_ch[i]] += pw;
+                if (ky > vs->key[v_ch[i]])
+                    vs->key[v_ch[i]] = ky;
+            }
+        }
+    }
 #ifdef CMHIP_EQ_STAMPS
     if (blockIdx.x == 7 && lane == 0 && a.dbg) {     // per-role busy cycles (tools/eq_stamps.py)
         a.dbg[2 * wave] = st_busy;
@@ -820,7 +822,7 @@ template <int NSEC>
 static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st)
 {
     // the int16 conversion and the VU window are per-sample work of the S waves: more of them
-    const bool heavy = a.out || a.vu;
+    const bool heavy = a.out || a.vu;      // (on the eight-wave layout these outputs run at 1.49 ms instead of 0.96)
     if (a.channels == 1)
         return heavy ? launch_eq_pipe<NSEC, 32, 4, 1>(a, st) : launch_eq_pipe<NSEC, 32, 1, 1>(a, st);
     if (a.channels == 2 && a.stride >= 16 && a.stride % 16 == 0)
