@@ -51,12 +51,6 @@ __device__ __forceinline__ int f32_to_i16(float y)
 // without a recurrence is spread over T lanes, where a 64-frame row costs 2 reads + 2 writes.
 // Rows are 68 floats (16-byte aligned, lane-per-row b128 access without bank conflicts).
 
-#ifndef CMHIP_EQ_RLAG
-#define CMHIP_EQ_RLAG 1           // R waves load the next row into registers a step ahead (0: same step)
-#endif
-#ifndef CMHIP_EQ_RSLOTS
-#define CMHIP_EQ_RSLOTS 1         // row slots (of 8) whose stores each R wave takes when the output is float planes only
-#endif
 #ifndef CMHIP_EQ_ABL
 #define CMHIP_EQ_ABL 0            // `make abl`: timing-only builds with one part of the pipeline cut out
 #endif
@@ -71,65 +65,41 @@ __device__ __forceinline__ int f32_to_i16(float y)
 // Wave order.  Waves w, w+4 and w+8 of a workgroup share a SIMD, and a step lasts as long as
 // the most loaded SIMD needs (issue slots plus the time its waves are blocked on LDS writes):
 // per step an R wave costs ~1100 clk of that, a T-in wave (load, gain, section 0) ~600, a
-// T-ff wave (feed-forward of the later sections, 16 rows) ~850, the S wave ~600.  The order
-// below pairs them so that no SIMD carries much more than a quarter of the total.
-enum : u32 { EQ_R = 0x00, EQ_TIN = 0x10, EQ_TFF = 0x20, EQ_S = 0x30, EQ_TS = 0x40 };   // TS: T-ff and S in one wave
+// T-ff wave (feed-forward of the later sections, 16 rows) ~850, an S wave 100-350.  The order
+// below gives every SIMD one long wave, one T-in wave and one S wave:
+//   {T-ff1, T-in0, S0}  {R0, T-in1, S1}  {R1, T-in2, S2}  {T-ff0, T-in3, S3}
+// (measured against eight-wave layouts with the store work on the R / T-ff waves: 0.91 ms
+// against 0.97-1.03 ms on config 3, 0.96 against 1.49 ms with int16 + VU outputs).
+enum : u32 { EQ_R = 0x00, EQ_TIN = 0x10, EQ_TFF = 0x20, EQ_S = 0x30 };
+constexpr u32 EQ_NSW = 4;                        // S waves
 
-// waves of a workgroup: float planes only (NSW == 1) -> the store work rides on the T-ff waves
-// (8 waves: two per SIMD, 256 VGPRs each); int16 / VU outputs (NSW == 4) -> S waves of their own
-template <int NSEC, int G, int NSW>
+template <int NSEC, int G>
 constexpr u32 eq_waves()
 {
     constexpr u32 nrw = (NSEC + 64 / G - 1) / (64 / G);
-    return NSW == 1 ? (NSEC > 1 ? nrw + G / 8 + 2 : nrw + G / 8 + 1) : nrw + G / 8 + (NSEC > 1 ? 2 : 0) + NSW;
+    return nrw + G / 8 + (NSEC > 1 ? 2 : 0) + EQ_NSW;
 }
 
-template <int NRW, int NTF, int NSW>
+template <int NRW, int NTF>
 __device__ __forceinline__ u32 eq_role(u32 wave)
 {
-    if constexpr (NTF == 2 && NSW == 1) {
-        if constexpr (NRW == 2) {                // SIMDs: {R0 Tin0} {R1 Tin1} {TS0 Tin2} {TS1 Tin3}
-#if defined(CMHIP_EQ_ORDER) && CMHIP_EQ_ORDER == 1   // {R0 TS0} {R1 TS1} {Tin0 Tin2} {Tin1 Tin3}
-            constexpr unsigned char t[8] = {EQ_R | 0, EQ_R | 1, EQ_TIN | 0, EQ_TIN | 1, EQ_TS | 0, EQ_TS | 1,
-                                            EQ_TIN | 2, EQ_TIN | 3};
-#elif defined(CMHIP_EQ_ORDER) && CMHIP_EQ_ORDER == 2 // {R0 Tin0} {R1 TS0} {Tin1 TS1} {Tin2 Tin3}
-            constexpr unsigned char t[8] = {EQ_R | 0, EQ_R | 1, EQ_TIN | 1, EQ_TIN | 2, EQ_TIN | 0, EQ_TS | 0,
-                                            EQ_TS | 1, EQ_TIN | 3};
-#elif defined(CMHIP_EQ_ORDER) && CMHIP_EQ_ORDER == 3 // {R0 R1} {TS0 TS1} {Tin0 Tin1} {Tin2 Tin3}
-            constexpr unsigned char t[8] = {EQ_R | 0, EQ_TS | 0, EQ_TIN | 0, EQ_TIN | 2, EQ_R | 1, EQ_TS | 1,
-                                            EQ_TIN | 1, EQ_TIN | 3};
-#else
-            constexpr unsigned char t[8] = {EQ_R | 0, EQ_R | 1, EQ_TS | 0, EQ_TS | 1, EQ_TIN | 0, EQ_TIN | 1,
-                                            EQ_TIN | 2, EQ_TIN | 3};
-#endif
-            return t[wave];
-        } else {                                 // {R0 TS0} {Tin0 TS1} {Tin1 Tin3} {Tin2}
-            constexpr unsigned char t[7] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 1, EQ_TIN | 2, EQ_TS | 0, EQ_TS | 1,
-                                            EQ_TIN | 3};
-            return t[wave];
-        }
-    } else if constexpr (NTF == 2) {
-        if constexpr (NRW == 2) {                // {Tff1 Tin0 S0} {R0 Tin1 S1} {R1 Tin2 S2} {Tff0 Tin3 S3}
-            constexpr unsigned char t[12] = {EQ_TFF | 1, EQ_R | 0, EQ_R | 1, EQ_TFF | 0, EQ_TIN | 0, EQ_TIN | 1,
-                                             EQ_TIN | 2, EQ_TIN | 3, EQ_S | 0, EQ_S | 1, EQ_S | 2, EQ_S | 3};
-            return t[wave];
-        } else {
-            constexpr unsigned char t[11] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 2, EQ_TIN | 3, EQ_S | 0, EQ_TIN | 1,
-                                             EQ_TFF | 0, EQ_TFF | 1, EQ_S | 1, EQ_S | 2, EQ_S | 3};
-            return t[wave];
-        }
-    } else if constexpr (NSW == 1) {             // one section: no T-ff waves
-        constexpr unsigned char t[6] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 1, EQ_TIN | 2, EQ_S | 0, EQ_TIN | 3};
+    if constexpr (NTF == 2 && NRW == 2) {        // three or four sections
+        constexpr unsigned char t[12] = {EQ_TFF | 1, EQ_R | 0, EQ_R | 1, EQ_TFF | 0, EQ_TIN | 0, EQ_TIN | 1,
+                                         EQ_TIN | 2, EQ_TIN | 3, EQ_S | 0, EQ_S | 1, EQ_S | 2, EQ_S | 3};
         return t[wave];
-    } else {
+    } else if constexpr (NTF == 2) {             // two sections: one R wave
+        constexpr unsigned char t[11] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 2, EQ_TIN | 3, EQ_S | 0, EQ_TIN | 1,
+                                         EQ_TFF | 0, EQ_TFF | 1, EQ_S | 1, EQ_S | 2, EQ_S | 3};
+        return t[wave];
+    } else {                                     // one section: no T-ff waves
         constexpr unsigned char t[9] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 1, EQ_TIN | 2, EQ_S | 0, EQ_TIN | 3,
                                         EQ_S | 1, EQ_S | 2, EQ_S | 3};
         return t[wave];
     }
 }
 
-template <int NSEC, int G, int NSW, int CH>
-__global__ __launch_bounds__((eq_waves<NSEC, G, NSW>() * 64))
+template <int NSEC, int G, int CH>
+__global__ __launch_bounds__((eq_waves<NSEC, G>() * 64))
 void k_eq_pipe(EqArgs a)
 {
     constexpr bool MONO = CH == 1, STEREO = CH == 2;
@@ -145,10 +115,8 @@ void k_eq_pipe(EqArgs a)
     constexpr u32 SPR = EP_TB / 4;                // store lanes per row (4 frames each)
     constexpr u32 RPI = 64 / SPR;                 // rows per store instruction
     constexpr int DPP_SHR1 = 0x111, DPP_SHL7 = 0x107;
-    // the register prefetch of the R waves needs 128 VGPRs for two rows: only where the workgroup
-    // has at most two waves per SIMD (256 VGPRs each); with S waves of their own it would spill
-    constexpr bool RLAG = CMHIP_EQ_RLAG && eq_waves<NSEC, G, NSW>() <= 8;
-    constexpr u32 HOP = RLAG ? 3 : 2;             // steps from F_k to F_k+1
+    constexpr u32 HOP = 2;                        // steps from F_k to F_k+1
+    constexpr u32 NSW = EQ_NSW;
     extern __shared__ float lds[];                // NBUF buffers x 2 slots x EP_TILE floats, then G counts
     u32 *nfr_lds = reinterpret_cast<u32 *>(lds + NBUF * 2 * EP_TILE);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -168,22 +136,15 @@ void k_eq_pipe(EqArgs a)
         return r < rows_here ? q : 0xffffffffu;           // (q >= streams: past the end of the batch)
     };
 
-    const u32 role = eq_role<(int)NRW, (int)NTF, NSW>(wave);
+    const u32 role = eq_role<(int)NRW, (int)NTF>(wave);
     const bool is_rec = (role & 0xf0u) == EQ_R;
     const bool is_tin = (role & 0xf0u) == EQ_TIN;
-    const bool is_tff = (role & 0xf0u) == EQ_TFF || (role & 0xf0u) == EQ_TS;
-    // store work: the G / 4 row slots (four rows each) of Y_last are dealt out by role.  Float planes
-    // only, three or four sections: CMHIP_EQ_RSLOTS slots to each R wave, the rest to the T-ff waves
-    // (evens the SIMDs out); two sections: half to each T-ff wave; otherwise the S waves share them.
-    constexpr bool S_ON_R = NSW == 1 && NRW == 2 && NTF == 2;
+    const bool is_tff = (role & 0xf0u) == EQ_TFF;
+    // store work: the G / 4 row slots (four rows each) of Y_last, shared out among the S waves
     constexpr u32 NSLOT = G / 4;
-    constexpr u32 RSL = CMHIP_EQ_RSLOTS, TSL = (NSLOT - 2 * RSL) / 2;    // slots of an R / a T-ff wave (S_ON_R)
-    constexpr u32 NSL = S_ON_R ? (RSL > TSL ? RSL : TSL) : (NSW == 1 && NTF == 2) ? NSLOT / 2 : NSLOT / NSW;
-    u32 s_first = 0, s_cnt = 0;                           // (NSL: most slots of a wave)
-    if (S_ON_R) {
-        if ((role & 0xf0u) == EQ_R) { s_first = RSL * (role & 15u); s_cnt = RSL; }
-        if ((role & 0xf0u) == EQ_TS) { s_first = 2u * RSL + TSL * (role & 15u); s_cnt = TSL; }
-    } else if ((role & 0xf0u) == EQ_S || (role & 0xf0u) == EQ_TS) {
+    constexpr u32 NSL = NSLOT / NSW;                      // slots of one S wave
+    u32 s_first = 0, s_cnt = 0;
+    if ((role & 0xf0u) == EQ_S) {
         s_first = NSL * (role & 15u);
         s_cnt = NSL;
     }
@@ -339,34 +300,23 @@ void k_eq_pipe(EqArgs a)
     u64 st_busy = 0, st_p[3] = {0, 0, 0};
     const u64 st_begin = __builtin_readcyclecounter();
 #endif
-    // Schedule (HOP = 3): F_k of block b is written in step b+3k, loaded into the R lanes'
-    // registers in step b+3k+1 while they still work on block b-1, turned into Y_k in step
-    // b+3k+2, and the block leaves in step b+3*NSEC.  Every buffer is read one step after it
-    // was written, so two slots per buffer are enough (the third copy is in VGPRs).
-    auto rec_step = [&](float4 (&v)[EP_TB / 4], float4 (&nxt)[EP_TB / 4], const u32 step) {
+    // Schedule: F_k of block b is written in step b+2k, Y_k in step b+2k+1, the block leaves in
+    // step b+2*NSEC.  Every buffer is read one step after it was written, so two slots do.
+    // (Loading an R wave's next row into registers a step ahead was worth 7 % with eight waves
+    // per workgroup; with twelve it needs more registers than three waves per SIMD leave.)
+    auto rec_step = [&](const u32 step) {
         if (!(CMHIP_EQ_ABL & 32)) {
             const u32 first = HOP * sec + HOP - 1u;       // step in which block 0 is worked on
             const u32 b = step - first;
-            if (RLAG) {                                   // next block's row: into registers now
-                const u32 bp = b + 1u;
-                if (has_sec && step + 1u >= first && bp < nblocks) {
-                    const float4 *in = reinterpret_cast<const float4 *>(
-                        lds + ((2u * sec) * 2u + (bp & 1u)) * EP_TILE + row * EP_ROW);
-#pragma unroll
-                    for (u32 t = 0; t < EP_TB / 4; t++)
-                        nxt[t] = in[t];
-                }
-            }
             if (has_sec && step >= first && b < nblocks) {
                 float4 *out = reinterpret_cast<float4 *>(
                     lds + ((2u * sec + 1u) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW);
-                if (!RLAG) {
-                    const float4 *in = reinterpret_cast<const float4 *>(
-                        lds + ((2u * sec) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW);
+                const float4 *in = reinterpret_cast<const float4 *>(
+                    lds + ((2u * sec) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW);
+                float4 v[EP_TB / 4];
 #pragma unroll
-                    for (u32 t = 0; t < EP_TB / 4; t++)  // whole row first: 16 LDS reads in flight
-                        v[t] = in[t];
-                }
+                for (u32 t = 0; t < EP_TB / 4; t++)      // whole row first: 16 LDS reads in flight
+                    v[t] = in[t];
                 const u32 done = b * EP_TB;
                 const u32 cnt = my_nfr > done ? min(my_nfr - done, EP_TB) : 0u;
                 if (CMHIP_EQ_ABL & 4) {
@@ -509,9 +459,8 @@ void k_eq_pipe(EqArgs a)
     // eight (each with the history registers of its own rows)
     auto tff_step = [&](const u32 step) {
         if (!(CMHIP_EQ_ABL & (128 | 16))) {
-            // reads first, then arithmetic: one LDS latency per step where the registers allow
-            // it (two waves per SIMD), one per pass otherwise
-            constexpr u32 PG = RLAG ? PASSES : 1;         // passes whose rows are loaded together
+            // reads of every pass first, then arithmetic: one LDS latency per step
+            constexpr u32 PG = PASSES;
 #pragma unroll
             for (u32 p0 = 0; p0 < PASSES; p0 += PG) {
                 float4 yin[PG][NSEC][2];
@@ -689,34 +638,11 @@ void k_eq_pipe(EqArgs a)
     // count a T wave's outstanding loads); every wave passes the same number of barriers.
     const u32 nst2 = (nsteps + 1u) & ~1u;                 // an odd tail step finds nothing to do
     if (is_rec) {
-        float4 ra[EP_TB / 4], rb[EP_TB / 4];
-#pragma unroll
-        for (u32 t = 0; t < EP_TB / 4; t++)
-            ra[t] = rb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (S_ON_R) {                          // the recurrence first, then this wave's share of the stores
-            for (u32 step = 0; step < nst2; step += 2) {
-#if defined(CMHIP_EQ_V) && CMHIP_EQ_V == 1
-                EQ_STEP((s_step(step), rec_step(ra, rb, step)));
-                EQ_STEP((s_step(step + 1), rec_step(rb, ra, step + 1)));
-#else
-                EQ_STEP((rec_step(ra, rb, step), s_step(step)));
-                EQ_STEP((rec_step(rb, ra, step + 1), s_step(step + 1)));
-#endif
-            }
-        } else {
-            for (u32 step = 0; step < nst2; step += 2) {
-                EQ_STEP(rec_step(ra, rb, step));
-                EQ_STEP(rec_step(rb, ra, step + 1));
-            }
-        }
+        for (u32 step = 0; step < nst2; step++)
+            EQ_STEP(rec_step(step));
     } else if (is_store) {
-        if (is_tff) {                                     // float planes only: T-ff and S in one wave
-            for (u32 step = 0; step < nst2; step++)
-                EQ_STEP((tff_step(step), s_step(step)));
-        } else {
-            for (u32 step = 0; step < nst2; step++)
-                EQ_STEP(s_step(step));
-        }
+        for (u32 step = 0; step < nst2; step++)
+            EQ_STEP(s_step(step));
     } else if (is_tff) {
         for (u32 step = 0; step < nst2; step++)
             EQ_STEP(tff_step(step));
@@ -760,13 +686,13 @@ void k_eq_pipe(EqArgs a)
     if (blockIdx.x == 7 && lane == 0 && a.dbg) {     // per-role busy cycles (tools/eq_stamps.py)
         a.dbg[2 * wave] = st_busy;
         a.dbg[2 * wave + 1] = __builtin_readcyclecounter() - st_begin;
-        a.dbg[41 + wave] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_ID
-        a.dbg[40] = nsteps;
+        a.dbg[36 + wave] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_ID
+        a.dbg[48] = nsteps;
         if (is_tin && tw < 2) {                       // two T-in waves: phases inside a step
             for (int i = 0; i < 3; i++)
                 a.dbg[50 + 3 * tw + i] = st_p[i];
         }
-        a.dbg[20 + wave] = role;
+        a.dbg[24 + wave] = role;
     }
 #endif
 
@@ -795,14 +721,14 @@ static constexpr size_t eq_pipe_lds_bytes()
     return ((size_t)(2 * NSEC) * 2 * G * (64 + 4)) * sizeof(float) + G * sizeof(u32);
 }
 
-template <int NSEC, int G, int NSW, int CH>
+template <int NSEC, int G, int CH>
 static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
 {
     constexpr size_t lds_bytes = eq_pipe_lds_bytes<NSEC, G>();
     static_assert(lds_bytes <= 160 * 1024, "tiles of a workgroup must fit the LDS");
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G, NSW, CH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G, CH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess)
             return e;
@@ -811,8 +737,7 @@ static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
     const u64 rows = (u64)a.streams * (CH == 1 ? 1u : a.channels);      // one row per stream and channel
     const u32 spg = CH == 1 ? G : G / a.channels;
     const u32 grid = a.whole_streams ? (a.streams + spg - 1) / spg : (u32)((rows + G - 1) / G);
-    hipLaunchKernelGGL((k_eq_pipe<NSEC, G, NSW, CH>), dim3(grid),
-                       dim3(eq_waves<NSEC, G, NSW>() * 64), lds_bytes, st, a);
+    hipLaunchKernelGGL((k_eq_pipe<NSEC, G, CH>), dim3(grid), dim3(eq_waves<NSEC, G>() * 64), lds_bytes, st, a);
     return hipGetLastError();
 }
 
@@ -821,13 +746,11 @@ static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st)
 template <int NSEC>
 static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st)
 {
-    // the int16 conversion and the VU window are per-sample work of the S waves: more of them
-    const bool heavy = a.out || a.vu;      // (on the eight-wave layout these outputs run at 1.49 ms instead of 0.96)
     if (a.channels == 1)
-        return heavy ? launch_eq_pipe<NSEC, 32, 4, 1>(a, st) : launch_eq_pipe<NSEC, 32, 1, 1>(a, st);
+        return launch_eq_pipe<NSEC, 32, 1>(a, st);
     if (a.channels == 2 && a.stride >= 16 && a.stride % 16 == 0)
-        return heavy ? launch_eq_pipe<NSEC, 32, 4, 2>(a, st) : launch_eq_pipe<NSEC, 32, 1, 2>(a, st);
-    return heavy ? launch_eq_pipe<NSEC, 32, 4, 0>(a, st) : launch_eq_pipe<NSEC, 32, 1, 0>(a, st);
+        return launch_eq_pipe<NSEC, 32, 2>(a, st);
+    return launch_eq_pipe<NSEC, 32, 0>(a, st);
 }
 
 hipError_t launch_eq(const EqArgs &a, hipStream_t st)

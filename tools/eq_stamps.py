@@ -20,12 +20,12 @@ b.sync()
 out = (C.c_uint64 * 64)()
 cm.lib.cmhip_debug_read.argtypes = [C.c_void_p, C.c_void_p]
 assert cm.lib.cmhip_debug_read(b.h, out) == 0
-nsteps = out[40]
+nsteps = out[48]
 print("G =", os.environ.get("CMHIP_EQ_G", "default"), "steps", nsteps)
-for w in range(16):
+for w in range(12):
     if out[2 * w + 1] > nsteps:
-        hw = out[41 + w]
-        role = {0: "R", 1: "Tin", 2: "Tff", 3: "S", 4: "Tff+S"}[(out[20 + w] >> 4) & 7] + str(out[20 + w] & 15)
+        hw = out[36 + w]
+        role = {0: "R", 1: "Tin", 2: "Tff", 3: "S", 4: "Tff+S"}[(out[24 + w] >> 4) & 7] + str(out[24 + w] & 15)
         print(f"wave {w:2d} {role:6s}: busy {out[2*w]/nsteps:8.1f} clk/step   total {out[2*w+1]/nsteps:8.1f} clk/step   "
               f"SIMD {(hw >> 4) & 3}  CU {(hw >> 8) & 15}  wave slot {hw & 15}")
 for i in range(2):
