@@ -99,6 +99,38 @@ def test_eq_config3_shape_sampled(gpu, oracle):
     b.close()
 
 
+def test_eq_config3_full_size_properties(gpu, oracle):
+    """BASELINE config 3 at full size (8192 mono streams x 65 536 frames, 3-band EQ, float planes):
+    sampled streams bit-equal to the oracle, and the same signal fed as two half blocks (filter
+    state carried across the launches) bit-equal to the one-block run on those streams."""
+    cm = gpu
+    S, T = 8192, 65536
+    coef = cm.eq3(48000.0)
+    b = cm.Batch(S, 1, T, flags=cm.EQ | cm.OUT_F32)
+    assert b.set_eq(-1, coef) == 0
+    assert b.set_gain(-1, 1, 1000, [900]) == 0
+    b.generate(cm.GEN_NOISE, 12345, T)
+    b.run(T)
+    pick = (0, 31, 32, 4095, 4096, 8191)
+    full = {}
+    for s in pick:
+        (wf, _), = _oracle_eq(oracle, coef, 3, (1, 1000, [900]), [oracle.lcg(12345 + s, T)])
+        full[s] = b.download_f32(s, 0, T).copy()
+        assert np.array_equal(full[s].view(np.uint32), wf.view(np.uint32)), s
+    b.close()
+    h = cm.Batch(S, 1, T // 2, flags=cm.EQ | cm.OUT_F32)
+    assert h.set_eq(-1, coef) == 0
+    assert h.set_gain(-1, 1, 1000, [900]) == 0
+    for half in range(2):
+        h.generate(cm.GEN_NOISE, 12345, T // 2, frame_offset=half * (T // 2))
+        h.run(T // 2)
+        for s in pick:
+            got = h.download_f32(s, 0, T // 2)
+            want = full[s][half * (T // 2):(half + 1) * (T // 2)]
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (s, half)
+    h.close()
+
+
 @pytest.mark.parametrize("nsec", [1, 2, 3, 4])
 def test_eq_pipelined_kernel_ragged_and_state_carry(gpu, oracle, nsec):
     """float-only batches take the pipelined kernel (k_eq_pipe): ragged stream ends inside

@@ -434,6 +434,41 @@ def test_full_size_config2_properties(gpu, oracle):
     v.close()
 
 
+def test_full_size_config4_total_on_one_gpu(gpu, oracle):
+    """BASELINE configs 4/5 hold 65 536 mono streams; all of them on ONE GPU at 65 536 frames are
+    8 GiB of PCM per array, so slot offsets pass 2^32 bytes (stream 32 768 starts at exactly 4 GiB).
+    Sampled streams on both sides of that line against the oracle; the node-global record of the
+    batch against the host merge of all 65 536 per-stream windows (a checksum of checksums)."""
+    import torch
+    cm = gpu
+    S, C, T = 65536, 1, 65536
+    b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU)
+    assert b.set_gain(-1, 1, 1000, [900]) == 0
+    b.generate(cm.GEN_NOISE, 12345, T)
+    b.run(T)
+    dst = torch.zeros(cm.NODE_WORDS, dtype=torch.int64, device="cuda:0")
+    b.node_partial(dst.data_ptr())
+    b.sync()
+    rc, node = cm.node_finish(dst.cpu().numpy(), C)
+    assert rc == 0 and node.frames == S * T
+    total, top = 0, 0
+    for s in range(S):
+        power, peak, frames = b.vu_raw(s)
+        assert frames == T, s
+        total += int(power[0])
+        top = max(top, abs(int(peak[0])))
+    assert node.channel_power[0] == oracle.lib.oracle_power_db(total, S * T)
+    assert abs(int(node.global_peak)) == top
+    res, rcs = b.vu_results()
+    assert all(r == 0 for r in rcs)
+    for s in (0, 1, 32767, 32768, 32769, 65535):
+        want = _oracle_block(oracle, oracle.lcg(12345 + s, T), C, (1, 1000, [900]), None)
+        assert np.array_equal(b.download(s, T), want), s
+        _, ro = _oracle_vu(oracle, [want], C)
+        assert res[s].as_dict() == of.vu_result_dict(ro), s
+    b.close()
+
+
 @pytest.mark.parametrize("C", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 def test_wide_channel_kernels(gpu, oracle, C):
     """more than two channels with identity maps take the vector kernels (k_run_wide for 4/8/16,
