@@ -14,11 +14,15 @@
  *
  * coolmic_group_pump() moves one block: it pulls up to block_frames from every
  * upstream handle into pinned staging (partial frames are carried to the next pump,
- * as ref: src/transform.c:155-160 does per read), uploads, runs the fused
- * channel-map/gain/VU kernel once over all streams, and downloads the PCM into the
- * streams' output queues.  A read on an empty downstream handle pumps by itself, so
- * a purely pull-driven chain works unchanged; streams are read ahead by at most
- * `queue_blocks` blocks, and parameter changes take effect at the next pump.
+ * as ref: src/transform.c:155-160 does per read) and queues upload, the fused
+ * channel-map/gain/VU kernel over all streams and the download on the GPU -- then it
+ * returns.  The block's PCM reaches the streams' output queues with the next pump or
+ * with the first read that finds a queue empty, so a host that pumps and reads in a
+ * loop reads block k while the GPU works on block k+1.  A read on an empty downstream
+ * handle first brings the block in flight home and only then pumps by itself, so a
+ * purely pull-driven chain works unchanged and never pulls more than it did; streams
+ * are read ahead by at most `queue_blocks` blocks (the block in flight counts; use
+ * >= 2 for the overlap), and parameter changes take effect at the next pump.
  */
 #ifndef __COOLMIC_DSP_GROUP_H__
 #define __COOLMIC_DSP_GROUP_H__
@@ -60,8 +64,9 @@ int                 coolmic_group_set_eq(coolmic_group_t *self, int slot, unsign
 /* transformed PCM of one stream; keeps the group alive while it lives */
 coolmic_iohandle_t *coolmic_group_get_iohandle(coolmic_group_t *self, unsigned int slot);
 
-/* one block for every stream whose queue has room.  Returns the number of streams that
- * delivered at least one frame, 0 when nothing moved, negative on error. */
+/* one block for every stream whose queue has room.  Returns the number of streams whose source
+ * delivered at least one frame to this block, 0 when no source had anything (the block that was
+ * in flight is in the queues then), negative on error. */
 int                 coolmic_group_pump(coolmic_group_t *self);
 
 /* VU window of one stream since its last result; COOLMIC_ERROR_INVAL while it holds no frame */

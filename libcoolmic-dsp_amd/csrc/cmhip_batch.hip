@@ -16,11 +16,10 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <atomic>
-#include <condition_variable>
-#include <mutex>
 #include <thread>
 #include <vector>
+
+#include "work_pool.h"
 
 extern "C" int coolmic_sine_period(uint_least32_t rate, int16_t *table, size_t *samples);
 
@@ -80,91 +79,6 @@ struct EventPair {
     hipEvent_t a, b;
 };
 
-// Small persistent worker pool for the dB finish of many windows (log10 + sqrt per
-// channel and stream): with thousands of streams per batch one host thread would take
-// about as long as the GPU needs for the next block.
-struct FinishPool {
-    // Helpers for the host-side dB finish of many windows.  Work is handed out in small chunks
-    // from a shared counter and the calling thread works too, so a helper that the OS does not
-    // schedule in time (busy hosts, CPU quotas) costs nothing: whoever runs takes the chunks.
-    static constexpr unsigned CHUNK = 64;
-    std::vector<std::thread> workers;
-    std::mutex m;
-    std::condition_variable cv_work, cv_done;
-    unsigned generation = 0, active = 0;
-    bool stop = false;
-    void (*fn)(void *, unsigned, unsigned) = nullptr;
-    void *arg = nullptr;
-    unsigned total = 0;
-    std::atomic<unsigned> next{0};
-
-    explicit FinishPool(unsigned n)
-    {
-        for (unsigned i = 0; i < n; i++)
-            workers.emplace_back([this] { loop(); });
-    }
-    ~FinishPool()
-    {
-        {
-            std::lock_guard<std::mutex> g(m);
-            stop = true;
-        }
-        cv_work.notify_all();
-        for (auto &t : workers)
-            t.join();
-    }
-    void drain(void (*f)(void *, unsigned, unsigned), void *a, unsigned tot)
-    {
-        for (;;) {
-            const unsigned lo = next.fetch_add(CHUNK, std::memory_order_relaxed);
-            if (lo >= tot)
-                return;
-            f(a, lo, lo + CHUNK < tot ? lo + CHUNK : tot);
-        }
-    }
-    void loop()
-    {
-        unsigned seen = 0;
-        for (;;) {
-            void (*f)(void *, unsigned, unsigned);
-            void *a;
-            unsigned tot;
-            {
-                std::unique_lock<std::mutex> g(m);
-                cv_work.wait(g, [&] { return stop || generation != seen; });
-                if (stop)
-                    return;
-                seen = generation;
-                f = fn;
-                a = arg;
-                tot = total;
-                active++;
-            }
-            drain(f, a, tot);
-            {
-                std::lock_guard<std::mutex> g(m);
-                if (--active == 0)
-                    cv_done.notify_one();
-            }
-        }
-    }
-    void run(void (*f)(void *, unsigned, unsigned), void *a, unsigned tot)
-    {
-        {
-            std::lock_guard<std::mutex> g(m);
-            fn = f;
-            arg = a;
-            total = tot;
-            next.store(0, std::memory_order_relaxed);
-            generation++;
-        }
-        cv_work.notify_all();
-        drain(f, a, tot);                             // the caller works as well
-        std::unique_lock<std::mutex> g(m);            // chunks taken by helpers may still be running
-        cv_done.wait(g, [&] { return active == 0; });
-    }
-};
-
 struct cmhip_batch {
     cmhip_batch_desc_t d;
     hipStream_t stream;
@@ -183,7 +97,7 @@ struct cmhip_batch {
     hipStream_t copy_stream;               // snapshots travel here, beside the next run
     hipEvent_t ev_main, ev_reset[3];
     bool reset_pending[3];
-    struct FinishPool *pool;
+    struct WorkPool *pool;
     uint32_t *d_nframes;
     EqParam *d_eq;
     EqState *d_eqstate;
@@ -1103,7 +1017,7 @@ extern "C" int cmhip_batch_vu_collect(cmhip_batch_t *b, coolmic_vumeter_result_t
         if (!b->pool) {
             unsigned n = std::thread::hardware_concurrency() / 2;
             n = n < 1 ? 1 : (n > 8 ? 8 : n);
-            b->pool = new FinishPool(n);
+            b->pool = new WorkPool(n);
         }
         b->pool->run(body, &job, b->d.streams);
     } else {

@@ -7,6 +7,8 @@
 
 #include <vector>
 
+#include "work_pool.h"
+
 #define COOLMIC_COMPONENT "libcoolmic-dsp/group"
 #include "host_internal.h"
 #include <coolmic-dsp/group.h>
@@ -26,10 +28,14 @@ struct coolmic_group {
     unsigned int channels, max_streams, queue_blocks;
     size_t block_frames;
     cmhip_batch_t *batch;
-    int16_t *h_in, *h_out;                   // pinned mirrors of the batch's PCM slots
+    int16_t *h_in[2], *h_out;                // pinned mirrors of the batch's PCM slots (input: two sets)
+    unsigned int cur;                        // input set the next pull fills
     size_t stride;                           // samples between slots
     std::vector<GroupStream> *streams;
-    std::vector<uint32_t> *nframes;
+    std::vector<uint32_t> *nframes;          // frames per stream of the block being pulled
+    std::vector<uint32_t> *flight;           // ... of the block on the GPU
+    bool in_flight;                          // upload + launch + download of a block are queued
+    WorkPool *pool;                          // helpers for the queue copies of large groups
 };
 
 struct GroupHandle {
@@ -46,8 +52,13 @@ static void group_destroy(void *self)
         delete g->streams;
     }
     delete g->nframes;
-    if (g->h_in)
-        (void)hipHostFree(g->h_in);
+    delete g->flight;
+    delete g->pool;
+    if (g->in_flight)                        // the copies of the last block still use the staging
+        (void)hipStreamSynchronize((hipStream_t)cmhip_batch_hip_stream(g->batch));
+    for (int i = 0; i < 2; i++)
+        if (g->h_in[i])
+            (void)hipHostFree(g->h_in[i]);
     if (g->h_out)
         (void)hipHostFree(g->h_out);
     cmhip_batch_free(g->batch);
@@ -90,17 +101,20 @@ extern "C" coolmic_group_t *coolmic_group_new(const char *name, igloo_ro_t assoc
     }
     g->stride = cmhip_batch_stride(g->batch);
     const size_t bytes = (size_t)max_streams * g->stride * sizeof(int16_t);
-    if (hipHostMalloc((void **)&g->h_in, bytes, hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc((void **)&g->h_in[0], bytes, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&g->h_in[1], bytes, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&g->h_out, bytes, hipHostMallocDefault) != hipSuccess) {
         coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_NOMEM,
-                            "pinned staging of %zu bytes x 2 failed", bytes);
+                            "pinned staging of %zu bytes x 3 failed", bytes);
         coolmic_ro_unref(g);
         return NULL;
     }
-    memset(g->h_in, 0, bytes);
+    memset(g->h_in[0], 0, bytes);
+    memset(g->h_in[1], 0, bytes);
     g->streams = new std::vector<GroupStream>();
     g->streams->reserve(max_streams);
     g->nframes = new std::vector<uint32_t>(max_streams, 0);
+    g->flight = new std::vector<uint32_t>(max_streams, 0);
     return g;
 }
 
@@ -158,6 +172,64 @@ extern "C" int coolmic_group_set_eq(coolmic_group_t *self, int slot, unsigned in
     return rc;
 }
 
+// The block on the GPU comes home: wait for its download and hand the PCM to the streams' queues.
+// With many streams the copies are shared out over a few helper threads (streams are independent).
+static int group_complete(coolmic_group_t *self)
+{
+    if (!self->in_flight)
+        return COOLMIC_ERROR_NONE;
+    self->in_flight = false;
+    if (hipStreamSynchronize((hipStream_t)cmhip_batch_hip_stream(self->batch)) != hipSuccess) {
+        coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_GENERIC,
+                            "HIP group block failed: %s", cmhip_last_error());
+        return COOLMIC_ERROR_GENERIC;
+    }
+    const size_t n = self->streams->size();
+    const size_t framesize = 2u * self->channels;
+    const size_t queue_cap = self->block_frames * framesize * self->queue_blocks;
+    struct Job {
+        coolmic_group_t *g;
+        size_t framesize, queue_cap;
+    } job = {self, framesize, queue_cap};
+    auto body = [](void *p, unsigned lo, unsigned hi) {
+        Job *j = (Job *)p;
+        coolmic_group_t *g = j->g;
+        for (unsigned i = lo; i < hi; i++) {
+            const uint32_t fr = (*g->flight)[i];
+            if (!fr)
+                continue;
+            (*g->flight)[i] = 0;
+            GroupStream &s = (*g->streams)[i];
+            if (s.queue_pos == s.queue.size()) {
+                s.queue.clear();
+                s.queue_pos = 0;
+            } else if (s.queue_pos > j->queue_cap) {
+                s.queue.erase(s.queue.begin(), s.queue.begin() + (ptrdiff_t)s.queue_pos);
+                s.queue_pos = 0;
+            }
+            const unsigned char *src = (const unsigned char *)(g->h_out + i * g->stride);
+            s.queue.insert(s.queue.end(), src, src + (size_t)fr * j->framesize);
+        }
+    };
+    size_t bytes = 0;
+    for (size_t i = 0; i < n; i++)
+        bytes += (size_t)(*self->flight)[i] * framesize;
+    if (bytes >= (4u << 20) && n >= 64) {            // worth waking helpers for
+        if (!self->pool) {
+            unsigned t = std::thread::hardware_concurrency() / 2;
+            self->pool = new WorkPool(t < 1 ? 1 : (t > 6 ? 6 : t));
+        }
+        self->pool->run(body, &job, (unsigned)n, (unsigned)(n / 32 ? n / 32 : 1));
+    } else {
+        body(&job, 0, (unsigned)n);
+    }
+    return COOLMIC_ERROR_NONE;
+}
+
+// One block: pull from every source into pinned staging, then (the previous block being home)
+// queue upload, launch and download of this one and return -- the GPU and the copies work while
+// the caller reads the queues and the next pump pulls.  The block's PCM reaches the queues with
+// the next pump, or with the first read that finds a queue empty.
 extern "C" int coolmic_group_pump(coolmic_group_t *self)
 {
     if (!self)
@@ -168,6 +240,7 @@ extern "C" int coolmic_group_pump(coolmic_group_t *self)
     const size_t framesize = 2u * self->channels;
     const size_t block_bytes = self->block_frames * framesize;
     const size_t queue_cap = block_bytes * self->queue_blocks;
+    int16_t *h_in = self->h_in[self->cur];
     uint32_t most = 0;
     int delivered = 0;
 
@@ -175,9 +248,10 @@ extern "C" int coolmic_group_pump(coolmic_group_t *self)
     for (size_t i = 0; i < n; i++) {
         GroupStream &s = (*self->streams)[i];
         (*self->nframes)[i] = 0;
-        if (s.queue.size() - s.queue_pos + block_bytes > queue_cap)
+        const size_t coming = self->in_flight ? (size_t)(*self->flight)[i] * framesize : 0;
+        if (s.queue.size() - s.queue_pos + coming + block_bytes > queue_cap)
             continue;                          // this stream's reader is behind: no read-ahead
-        unsigned char *dst = (unsigned char *)(self->h_in + i * self->stride);
+        unsigned char *dst = (unsigned char *)(h_in + i * self->stride);
         size_t have = 0;
         if (s.carry_fill) {
             memcpy(dst, s.carry, s.carry_fill);
@@ -200,39 +274,29 @@ extern "C" int coolmic_group_pump(coolmic_group_t *self)
         if (fr)
             delivered++;
     }
+
+    // 2. the block before this one: its download was queued a pump ago
+    if (group_complete(self) != COOLMIC_ERROR_NONE)
+        return COOLMIC_ERROR_GENERIC;
     if (most == 0)
         return 0;
 
-    // 2. one upload, one launch, one download for the whole group
+    // 3. one upload, one launch, one download for the whole group, all queued on the batch's stream
     hipStream_t st = (hipStream_t)cmhip_batch_hip_stream(self->batch);
     const size_t span = ((n - 1) * self->stride + (size_t)most * self->channels) * sizeof(int16_t);
-    if (hipMemcpyAsync(cmhip_batch_dev_in(self->batch), self->h_in, span, hipMemcpyHostToDevice, st) !=
+    if (hipMemcpyAsync(cmhip_batch_dev_in(self->batch), h_in, span, hipMemcpyHostToDevice, st) !=
             hipSuccess ||
         cmhip_batch_run(self->batch, most, self->nframes->data()) != COOLMIC_ERROR_NONE ||
         hipMemcpyAsync(self->h_out, cmhip_batch_dev_out(self->batch), span, hipMemcpyDeviceToHost, st) !=
-            hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) {
+            hipSuccess) {
         coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_GENERIC,
                             "HIP group block failed: %s", cmhip_last_error());
+        (void)hipStreamSynchronize(st);
         return COOLMIC_ERROR_GENERIC;
     }
-
-    // 3. hand the PCM to the streams' queues
-    for (size_t i = 0; i < n; i++) {
-        const uint32_t fr = (*self->nframes)[i];
-        if (!fr)
-            continue;
-        GroupStream &s = (*self->streams)[i];
-        if (s.queue_pos == s.queue.size()) {
-            s.queue.clear();
-            s.queue_pos = 0;
-        } else if (s.queue_pos > queue_cap) {
-            s.queue.erase(s.queue.begin(), s.queue.begin() + (ptrdiff_t)s.queue_pos);
-            s.queue_pos = 0;
-        }
-        const unsigned char *src = (const unsigned char *)(self->h_out + i * self->stride);
-        s.queue.insert(s.queue.end(), src, src + (size_t)fr * framesize);
-    }
+    std::swap(self->nframes, self->flight);
+    self->in_flight = true;
+    self->cur ^= 1u;
     return delivered;
 }
 
@@ -246,10 +310,13 @@ static ssize_t group_handle_read(void *userdata, void *buffer, size_t len)
     len -= len % framesize;
     if (len == 0)
         return 0;
-    if (s.queue_pos == s.queue.size()) {         // nothing buffered: move one block
-        const int rc = coolmic_group_pump(g);
-        if (rc < 0)
+    if (s.queue_pos == s.queue.size()) {         // nothing buffered: the block on the GPU, else a new one
+        if (group_complete(g) != COOLMIC_ERROR_NONE)
             return -1;
+        if (s.queue_pos == s.queue.size()) {
+            if (coolmic_group_pump(g) < 0 || group_complete(g) != COOLMIC_ERROR_NONE)
+                return -1;
+        }
     }
     size_t avail = s.queue.size() - s.queue_pos;
     if (avail > len)
@@ -267,6 +334,8 @@ static int group_handle_eof(void *userdata)
     GroupStream &s = (*h->group->streams)[h->slot];
     if (s.queue_pos != s.queue.size())
         return 0;
+    if (h->group->in_flight && (*h->group->flight)[h->slot])
+        return 0;                              // frames of this stream are on their way
     if (!s.source)
         return 1;
     return coolmic_iohandle_eof(s.source);

@@ -12,13 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBDIR = os.path.join(ROOT, "libcoolmic-dsp_amd", "lib")
 
 
-def _build_and_run(tmp_path, name):
+def _build_and_run(tmp_path, name, *args):
     exe = tmp_path / name
     subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-O2",
                     "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".c"),
                     "-L", LIBDIR, "-lcoolmic-dsp-hip", "-Wl,-rpath," + LIBDIR, "-o", str(exe)],
                    check=True)
-    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=120)
+    out = subprocess.run([str(exe)] + [str(a) for a in args], check=True, capture_output=True, text=True,
+                         timeout=120)
     return out.stdout.strip().splitlines()
 
 
@@ -46,3 +47,15 @@ def test_batch_block_in_c(gpu, oracle, tmp_path):
         assert ("power %.17g dB" % r.global_power) in line
         if s == 0:
             assert ("first frame %d %d," % (want[0], want[1])) in line
+
+
+def test_group_server_in_c(gpu, golden, tmp_path):
+    """A many-stream host loop on the operator API (group.h): 94 blocks of 512 frames of the 48 kHz
+    sine at unity gain are golden vector G1 on every stream, however the blocks were pipelined."""
+    lines = _build_and_run(tmp_path, "group_server", 8, 512, 92)
+    exp = golden["cases"]["G1"]["vu"]
+    assert lines[0].startswith("streams 8 block 512:")
+    assert len(lines) == 3
+    for line, s in zip(lines[1:], (0, 7)):
+        assert line == "stream %d: frames %d peak %d power %.17g" % (
+            s, exp["frames"], exp["global_peak"], exp["global_power"])
