@@ -105,8 +105,33 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
                 const u32x4 ov = {o[0], o[1], o[2], o[3]};
                 __builtin_nontemporal_store(ov, dst + v);
             }
-            if constexpr (WRITE_F32)
+            if constexpr (WRITE_F32 && C == 1 && FULL) {
+                // Mono plane, every lane of the wave holding a whole vector: a lane's eight floats
+                // are a 32-byte run, so storing them lane by lane would fill half of every line per
+                // instruction.  The 512 floats of this step trade places through 2 KiB of LDS
+                // instead and leave as two whole-line 16-byte stores per lane.
+                __shared__ __attribute__((aligned(16))) float fst[64 * 8];
+                constexpr float kf = 1.0f / 32768.0f;
+                float f[8];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    f[2 * i] = (float)(int)(short)(o[i] & 0xffffu) * kf;
+                    f[2 * i + 1] = (float)((int)o[i] >> 16) * kf;
+                }
+                __syncthreads();                 // (one wave: the reads of the previous step are done)
+                float4 *wr = reinterpret_cast<float4 *>(fst) + 2u * lane;
+                wr[0] = make_float4(f[0], f[1], f[2], f[3]);
+                wr[1] = make_float4(f[4], f[5], f[6], f[7]);
+                __syncthreads();
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const float4 r0 = reinterpret_cast<const float4 *>(fst)[lane];
+                const float4 r1 = reinterpret_cast<const float4 *>(fst)[64u + lane];
+                f32x4 *pd = reinterpret_cast<f32x4 *>(f32s + (u64)(v0 + 64u * u) * 8) + lane;
+                __builtin_nontemporal_store(f32x4{r0.x, r0.y, r0.z, r0.w}, pd);
+                __builtin_nontemporal_store(f32x4{r1.x, r1.y, r1.z, r1.w}, pd + 64);
+            } else if constexpr (WRITE_F32) {
                 store_f32<C>(f32s, a.plane, v, o);
+            }
         } else if (tail[u]) {
             for (u32 j = 0; j < ntail; j++) {
                 u32 ow = 0;
