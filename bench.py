@@ -61,6 +61,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip ceilings / VU-only line")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, rank 0's JSON: whatever libraries print on the way (gloo
+    # announces its connections on stdout) goes to stderr with everything else
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -378,8 +384,10 @@ def main():
     if need_torch:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 def cpu_baseline(workload, channels):
