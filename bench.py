@@ -338,7 +338,7 @@ def main():
         v.sync()
         v.timing(True)
         v.timing_read()
-        for _ in range(10):
+        for _ in range(30):
             v.run(T)
         ms, n = v.timing_read()
         v.close()
@@ -361,12 +361,12 @@ def main():
                 if eqz:
                     o.set_eq(-1, cm.eq3(48000.0))
                 o.generate(cm.GEN_NOISE, 12345, t_)
-                for _ in range(2):
+                for _ in range(3):
                     o.run(t_)
                 o.sync()
                 o.timing(True)
                 o.timing_read()
-                for _ in range(5):
+                for _ in range(20):
                     o.run(t_)
                 ms, n = o.timing_read()
                 o.close()
