@@ -43,7 +43,14 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
 
     const StreamParam *p = a.param + s;
     const u32 magic = p->magic, shift = p->shift, perm2 = p->perm2;
-    const u32 g2lo = p->gain2[0], g2hi = p->gain2[C - 1];    // gains of the two dword halves
+    // Stereo, nothing but the VU window asked for, and the stream's map the identity or the swap:
+    // the samples stay where they are and the two halves of a dword change roles instead (sw = 1:
+    // the low half is output channel 1) -- one v_perm_b32 per dword less.  A map that repeats a
+    // channel, and every run that writes PCM or floats, permutes as before.
+    constexpr bool ROLES = C == 2 && DO_VU && !WRITE_PCM && !WRITE_F32;
+    const bool keep = ROLES && (perm2 == 0x03020100u || perm2 == 0x01000302u);
+    const u32 sw = keep && perm2 == 0x01000302u ? 1u : 0u;
+    const u32 g2lo = p->gain2[sw ? C - 1 : 0], g2hi = p->gain2[sw ? 0 : C - 1];    // gains of the two dword halves
 
     const int16_t *ins = a.in + (u64)s * a.stride;
     const u32x4 *src = reinterpret_cast<const u32x4 *>(ins);
@@ -74,6 +81,16 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
         }
     }
 
+    if constexpr (ROLES) {
+        if (!keep) {                             // (uniform: a wave works on one stream)
+#pragma unroll
+            for (u32 u = 0; u < TILE_U; u++)
+#pragma unroll
+                for (u32 i = 0; i < 4; i++)
+                    x[u][i] = __builtin_amdgcn_perm(x[u][i], x[u][i], perm2);
+        }
+    }
+
     // ---- arithmetic
     u32 qw[TILE_U][4];                           // packed magnitudes, kept for the epilogue
     PowAcc pw[2] = {{0, 0, 0}, {0, 0, 0}};
@@ -84,7 +101,7 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
         u32 o[4], vmax = 0;
 #pragma unroll
         for (u32 i = 0; i < 4; i++) {
-            if constexpr (C == 2)
+            if constexpr (C == 2 && !ROLES)
                 x[u][i] = __builtin_amdgcn_perm(x[u][i], x[u][i], perm2);   // stereo channel map
             qw[u][i] = gain2(x[u][i], g2lo, g2hi, magic, shift, o[i]);
             if constexpr (DO_VU) {
@@ -197,11 +214,12 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
                     neg = (X[j >> 1] >> (16u * (j & 1u) + 15u)) & 1u;
                 }
             }
-            gkey[c] = make_key(mag, base + 8ull * (v0 + 64u * uw + lw) + first, neg);
+            // (c counts dword halves here; with sw the half's output position is the other one of its frame)
+            gkey[c] = make_key(mag, base + 8ull * (v0 + 64u * uw + lw) + (first ^ sw), neg);
         }
-        if (lane < (u32)C) {
-            const u64 ssum = lane == 0 ? sum[0] : sum[1];
-            const u64 skey = lane == 0 ? gkey[0] : gkey[1];
+        if (lane < (u32)C) {                     // lane = output channel, fed by half lane ^ sw
+            const u64 ssum = (lane ^ sw) == 0 ? sum[0] : sum[1];
+            const u64 skey = (lane ^ sw) == 0 ? gkey[0] : gkey[1];
             if (ssum)
                 atomicAdd(&vs->power[lane], ssum);
             if (skey)
