@@ -347,6 +347,27 @@ def main():
                           "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
                           "Msamples_per_s_kernel": round(samples_per_step_rank / (ms / n * 1e-3) / 1e6, 1),
                           "algorithmic_bytes_per_sample": 2}
+        # the same read-only run with the transform as the reference creates it (gain disabled,
+        # ref: src/transform.c:107-108) and with every gain below the scale: shorter arithmetic
+        for key, g in (("vu_only_gain_disabled", None), ("vu_only_gains_below_scale", [900, 800][:Cn])):
+            v = cm.Batch(S, Cn, T, flags=cm.VU, device=local_rank)
+            if g is not None:
+                v.set_gain(-1, Cn, 1000, g)
+            if args.workload == "c2":
+                v.set_chmap(-1, [1, 0])
+            v.generate(cm.GEN_NOISE, 12345, T, first_global=rank, global_step=world)
+            for _ in range(3):
+                v.run(T)
+            v.sync()
+            v.timing(True)
+            v.timing_read()
+            for _ in range(30):
+                v.run(T)
+            ms, n = v.timing_read()
+            v.close()
+            gbs = samples_per_step_rank * 2 / (ms / n * 1e-3) / 1e9
+            out[key] = {"kernel_avg_ms": round(ms / n, 4), "achieved_GBs": round(gbs, 1),
+                        "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
 
     if rank == 0 and world == 1 and not args.no_extras and args.workload == "c2":
         # the other kernels of the path, kernel time only: never part of `value`

@@ -105,6 +105,8 @@ struct cmhip_batch {
     unsigned long long *d_dbg;             // 64 words, written only by diagnostic builds
 
     std::vector<StreamParam> h_param;
+    std::vector<GainShort> h_gshort;       // the shorter gain forms (read-only mono / stereo runs)
+    GainShort *d_gshort;
     std::vector<uint16_t> h_scale;         // the reference's master_gain_scale per stream
     std::vector<uint16_t> h_gain;          // [S][16]
     bool param_dirty;
@@ -151,6 +153,8 @@ static void host_magic(uint16_t scale, uint32_t *magic, uint32_t *shift)
 static void rebuild_param(cmhip_batch_t *b, unsigned int s)
 {
     StreamParam &p = b->h_param[s];
+    GainShort &q = b->h_gshort[s];
+    q = GainShort{};
     const uint16_t scale = b->h_scale[s];
     bool unity = scale != 0;                // trunc(x * g / g) == x: same as disabled
     for (unsigned c = 0; unity && c < b->d.channels; c++)
@@ -159,10 +163,19 @@ static void rebuild_param(cmhip_batch_t *b, unsigned int s)
         host_magic(1, &p.magic, &p.shift);
         for (unsigned c = 0; c < MAX_CH; c++)
             p.gain2[c] = 2u;
+        q.mode = GAIN_IDENTITY;
     } else {
         host_magic(scale, &p.magic, &p.shift);
-        for (unsigned c = 0; c < MAX_CH; c++)
-            p.gain2[c] = 2u * (uint32_t)b->h_gain[(size_t)s * MAX_CH + c];
+        bool below = true;
+        for (unsigned c = 0; c < MAX_CH; c++) {
+            const uint32_t g = b->h_gain[(size_t)s * MAX_CH + c];
+            p.gain2[c] = 2u * g;
+            if (c < 2)                       // ceil(g * 2^32 / scale); below 2^32 exactly when g < scale
+                q.kmul[c] = g < scale ? (uint32_t)((((uint64_t)g << 32) + scale - 1) / scale) : 0u;
+            if (c < b->d.channels && g >= scale)
+                below = false;
+        }
+        q.mode = below ? GAIN_BELOW_SCALE : GAIN_GENERAL;
     }
     bool ident = true;
     for (unsigned c = 0; c < b->d.channels; c++)
@@ -204,6 +217,7 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     }
     (void)hipFree(b->d_f32);
     (void)hipFree(b->d_param);
+    (void)hipFree(b->d_gshort);
     for (int i = 0; i < 3; i++)
         (void)hipFree(b->d_vu2[i]);
     delete b->pool;
@@ -283,6 +297,7 @@ static int batch_init(cmhip_batch_t *b)
         HIP_TRY(hipMemsetAsync(b->d_f32, 0, fbytes, b->stream));
     }
     HIP_TRY(hipMalloc((void **)&b->d_param, S * sizeof(StreamParam)));
+    HIP_TRY(hipMalloc((void **)&b->d_gshort, S * sizeof(GainShort)));
     for (int i = 0; i < 3; i++) {
         HIP_TRY(hipMalloc((void **)&b->d_vu2[i], S * sizeof(VuState)));
         HIP_TRY(hipMemsetAsync(b->d_vu2[i], 0, S * sizeof(VuState), b->stream));
@@ -312,6 +327,7 @@ static int batch_init(cmhip_batch_t *b)
         HIP_TRY(hipEventCreateWithFlags(&b->stage_ev[i], hipEventDisableTiming));
 
     b->h_param.assign(S, StreamParam{});
+    b->h_gshort.assign(S, GainShort{});
     b->h_scale.assign(S, 0);
     b->h_gain.assign(S * MAX_CH, 0);
     for (size_t s = 0; s < S; s++) {
@@ -356,6 +372,7 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->in_flight = false;
     b->d_f32 = nullptr;
     b->d_param = nullptr;
+    b->d_gshort = nullptr;
     b->d_vu = nullptr;
     b->d_vu2[0] = b->d_vu2[1] = b->d_vu2[2] = nullptr;
     b->cur = 0;
@@ -782,6 +799,8 @@ static int flush_params(cmhip_batch_t *b)
                 b->all_identity = false;
         HIP_TRY(hipMemcpyAsync(b->d_param, b->h_param.data(), b->h_param.size() * sizeof(StreamParam),
                                hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->d_gshort, b->h_gshort.data(), b->h_gshort.size() * sizeof(GainShort),
+                               hipMemcpyHostToDevice, b->stream));
         b->param_dirty = false;
     }
     if (b->eq_dirty) {
@@ -861,6 +880,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.out = (b->d.flags & CMHIP_OUT_PCM) ? b->d_out : nullptr;
         a.f32 = b->d_f32;
         a.param = b->d_param;
+        a.gshort = b->d_gshort;
         a.vu = vu ? b->d_vu : nullptr;
         a.nframes = frames_per_stream ? b->d_nframes : nullptr;
         a.frames = (uint32_t)frames;

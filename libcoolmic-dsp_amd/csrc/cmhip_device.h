@@ -106,6 +106,26 @@ __device__ __forceinline__ u32 gain2(u32 w, u32 g2lo, u32 g2hi, u32 magic, u32 s
     return qw;
 }
 
+// the shorter forms (StreamParam::mode): every gain below the scale -- one mulhi per sample, no
+// saturation (the quotient is below |x|) ...
+__device__ __forceinline__ u32 gain2_below(u32 w, u32 klo, u32 khi, u32 &out)
+{
+    const u32 sg = pk_sign(w);
+    const u32 aw = pk_sub(w ^ sg, sg);
+    const u32 q0 = __umulhi(aw & 0xffffu, klo);              // floor(|x|*gain/scale), exact (StreamParam)
+    const u32 q1 = __umulhi(aw >> 16, khi);
+    const u32 qw = __builtin_amdgcn_perm(q1, q0, 0x05040100u);   // both below 2^15: low halves side by side
+    out = pk_sub(qw ^ sg, sg);
+    return qw;
+}
+// ... and no gain at all: the magnitudes are the samples' own (32768 for -32768, as abs() in int gives)
+__device__ __forceinline__ u32 gain2_identity(u32 w, u32 &out)
+{
+    const u32 sg = pk_sign(w);
+    out = w;
+    return pk_sub(w ^ sg, sg);
+}
+
 // sum of squares with as few 64-bit additions as exactness allows: three squares
 // (each <= 2^30) fit a u32
 struct PowAcc {

@@ -16,6 +16,7 @@
 //   VU       ref: src/vumeter.c:161-177     first max-|x| peak, sum of squares
 //   float    ref: src/enc_vorbis.c:108-115  x / 32768.f, planar
 #include "cmhip_device.h"
+#include <type_traits>
 
 namespace cmhip {
 
@@ -51,6 +52,13 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
     const bool keep = ROLES && (perm2 == 0x03020100u || perm2 == 0x01000302u);
     const u32 sw = keep && perm2 == 0x01000302u ? 1u : 0u;
     const u32 g2lo = p->gain2[sw ? C - 1 : 0], g2hi = p->gain2[sw ? 0 : C - 1];    // gains of the two dword halves
+    // StreamParam::mode: the general form serves every stream; the shorter ones are taken where the
+    // VALU binds (a VU window, no PCM result, whole tiles).  The branch comes after the loads are out.
+    constexpr bool MODES = DO_VU && !WRITE_PCM && FULL;
+    const GainShort *gs = a.gshort + (MODES ? s : 0u);
+    const u32 mode = MODES ? uniform(gs->mode) : GAIN_GENERAL;
+    const u32 klo = MODES ? gs->kmul[sw ? C - 1 : 0] : 0u;
+    const u32 khi = MODES ? gs->kmul[sw ? 0 : C - 1] : 0u;
 
     const int16_t *ins = a.in + (u64)s * a.stride;
     const u32x4 *src = reinterpret_cast<const u32x4 *>(ins);
@@ -95,6 +103,9 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
     u32 qw[TILE_U][4];                           // packed magnitudes, kept for the epilogue
     PowAcc pw[2] = {{0, 0, 0}, {0, 0, 0}};
     u32 best[2] = {0, 0};                        // (magnitude << 16) | (U-1-u) << 6 | (63-lane)
+    __shared__ __attribute__((aligned(16))) float fst[WRITE_F32 && C == 1 && FULL ? 64 * 8 : 4];   // mono float planes
+    auto arithmetic = [&](auto mode_c) {
+    constexpr u32 MODE = decltype(mode_c)::value;
 #pragma unroll
     for (u32 u = 0; u < TILE_U; u++) {
         const u32 v = v0 + 64u * u + lane;
@@ -103,7 +114,12 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
         for (u32 i = 0; i < 4; i++) {
             if constexpr (C == 2 && !ROLES)
                 x[u][i] = __builtin_amdgcn_perm(x[u][i], x[u][i], perm2);   // stereo channel map
-            qw[u][i] = gain2(x[u][i], g2lo, g2hi, magic, shift, o[i]);
+            if constexpr (MODE == GAIN_IDENTITY)
+                qw[u][i] = gain2_identity(x[u][i], o[i]);
+            else if constexpr (MODE == GAIN_BELOW_SCALE)
+                qw[u][i] = gain2_below(x[u][i], klo, khi, o[i]);
+            else
+                qw[u][i] = gain2(x[u][i], g2lo, g2hi, magic, shift, o[i]);
             if constexpr (DO_VU) {
                 vmax = pk_max(vmax, qw[u][i]);
                 pw[0].add_lo(qw[u][i]);
@@ -127,7 +143,6 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
                 // are a 32-byte run, so storing them lane by lane would fill half of every line per
                 // instruction.  The 512 floats of this step trade places through 2 KiB of LDS
                 // instead and leave as two whole-line 16-byte stores per lane.
-                __shared__ __attribute__((aligned(16))) float fst[64 * 8];
                 constexpr float kf = 1.0f / 32768.0f;
                 float f[8];
 #pragma unroll
@@ -163,6 +178,17 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
                     f32s[(u64)(j % (u32)C) * a.plane + ((u64)v * 8 + j) / (u32)C] = q * (1.0f / 32768.0f);
             }
         }
+    }
+    };
+    if constexpr (MODES) {
+        if (mode == GAIN_IDENTITY)
+            arithmetic(std::integral_constant<u32, GAIN_IDENTITY>{});
+        else if (mode == GAIN_BELOW_SCALE)
+            arithmetic(std::integral_constant<u32, GAIN_BELOW_SCALE>{});
+        else
+            arithmetic(std::integral_constant<u32, GAIN_GENERAL>{});
+    } else {
+        arithmetic(std::integral_constant<u32, GAIN_GENERAL>{});
     }
 
     // ---- epilogue: one add and one max per channel into the stream's window
@@ -229,7 +255,7 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
 }
 
 template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U>
-__global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
+__device__ __forceinline__ void run_fast(const RunArgs &a)
 {
     constexpr u32 TILE_VEC = 64 * U;
     const u32 lane = threadIdx.x;
@@ -256,6 +282,20 @@ __global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
         fast_tile<C, WRITE_PCM, WRITE_F32, DO_VU, U, true>(a, s, k, nsamp, nfull, ntail, base, vs);
     else
         fast_tile<C, WRITE_PCM, WRITE_F32, DO_VU, U, false>(a, s, k, nsamp, nfull, ntail, base, vs);
+}
+
+template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U>
+__global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
+{
+    run_fast<C, WRITE_PCM, WRITE_F32, DO_VU, U>(a);
+}
+// The read-only entry (VU window, no PCM, no floats): at least three waves per SIMD -- the 16 KiB
+// tile holds 128 VGPRs of samples and magnitudes, and with the three arithmetic forms in one
+// function the allocator would otherwise take 170 and leave two.
+template <int C, int U>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_run_fast_ro(RunArgs a)
+{
+    run_fast<C, false, false, true, U>(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -714,12 +754,14 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
         const u32 grid = a.streams * b.chunks;
 #define CMHIP_FAST(C, P, F, V, U)                                                  \
     hipLaunchKernelGGL((k_run_fast<C, P, F, V, U>), dim3(grid), dim3(64), 0, st, b)
+#define CMHIP_FAST_RO(C, U)                                                        \
+    hipLaunchKernelGGL((k_run_fast_ro<C, U>), dim3(grid), dim3(64), 0, st, b)
 #define CMHIP_FAST_C(C)                                                            \
     do {                                                                           \
         if (pcm && !f32 && vu) CMHIP_FAST(C, true, false, true, 4);                \
-        else if (!pcm && !f32 && vu && tile_u == 4) CMHIP_FAST(C, false, false, true, 4);   \
-        else if (!pcm && !f32 && vu && tile_u == 8) CMHIP_FAST(C, false, false, true, 8);   \
-        else if (!pcm && !f32 && vu) CMHIP_FAST(C, false, false, true, 16);        \
+        else if (!pcm && !f32 && vu && tile_u == 4) CMHIP_FAST_RO(C, 4);           \
+        else if (!pcm && !f32 && vu && tile_u == 8) CMHIP_FAST_RO(C, 8);           \
+        else if (!pcm && !f32 && vu) CMHIP_FAST_RO(C, 16);                         \
         else if (pcm && !f32 && !vu) CMHIP_FAST(C, true, false, false, 4);         \
         else if (pcm && f32 && vu) CMHIP_FAST(C, true, true, true, 4);             \
         else if (!pcm && f32 && vu) CMHIP_FAST(C, false, true, true, 4);           \
@@ -731,6 +773,7 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
         else
             CMHIP_FAST_C(2);
 #undef CMHIP_FAST_C
+#undef CMHIP_FAST_RO
 #undef CMHIP_FAST
     } else if ((a.channels == 4 || a.channels == 8) && a.identity_maps &&
                !(a.channels == 4 && f32 && !getenv("CMHIP_WIDE4_F32"))) {

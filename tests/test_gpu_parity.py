@@ -245,6 +245,59 @@ def test_vu_only_and_float_outputs(gpu, oracle, C):
         b.close()
 
 
+@pytest.mark.parametrize("C", [1, 2])
+def test_short_gain_forms_of_the_read_only_runs(gpu, oracle, C):
+    """Runs with a VU window and no PCM result pick a shorter form of the gain arithmetic per stream
+    (StreamParam::mode): no gain / unity -> the samples' own magnitudes; every gain below the scale ->
+    one mulhi by ceil(gain * 2^32 / scale).  One batch mixes every case, on whole tiles and a ragged
+    end, with the extreme samples and the extreme constants; windows and float planes against the oracle."""
+    cm = gpu
+    rng = np.random.default_rng(600 + C)
+    T = 20011                                    # whole 16 KiB tiles and a ragged last one
+    cases = [None,                                                  # gain disabled
+             (C, 1000, [1000] * C),                                 # unity
+             (C, 1000, [900, 999][:C]),                             # below the scale
+             (C, 65535, [65534, 1][:C]),                            # extreme constants, below
+             (C, 3, [2, 0][:C]),                                    # a zero gain
+             (C, 32768, [32767, 16384][:C]),
+             (C, 1000, [750, 1250][:C] if C == 2 else [1001]),      # one gain above: general form
+             (1, 7, [6]),                                           # one value for every channel
+             (C, 1000, [1000, 999][:C])]                            # unity on one channel only
+    S = len(cases)
+    xs = []
+    for s in range(S):
+        x = _rand_pcm(rng, T * C, "full" if s % 2 == 0 else "edges")
+        x[:4] = [-32768, 32767, -32768, -1]
+        xs.append(x)
+    cmaps = [None, [1, 0]] if C == 2 else [None]
+    for cmap in cmaps:
+        wants = [_oracle_block(oracle, xs[s], C, cases[s], cmap) for s in range(S)]
+        for flags in (cm.VU, cm.OUT_F32 | cm.VU):
+            b = cm.Batch(S, C, T, flags=flags)
+            if cmap is not None:
+                assert b.set_chmap(-1, cmap) == 0
+            for s in range(S):
+                if cases[s] is not None:
+                    assert b.set_gain(s, *cases[s]) == 0
+                b.upload(s, xs[s])
+            for lo, hi in ((0, T // 2 + 3), (T // 2 + 3, T)):       # two launches, one window
+                if lo:
+                    for s in range(S):
+                        b.upload(s, xs[s][lo * C:])
+                b.run(hi - lo)
+                if flags & cm.OUT_F32:
+                    for s in range(S):
+                        planar = oracle.to_f32_planar(wants[s][lo * C:hi * C], C)
+                        for c in range(C):
+                            got = b.download_f32(s, c, hi - lo)
+                            assert np.array_equal(got.view(np.uint32), planar[c].view(np.uint32)), (s, c)
+            for s in range(S):
+                rc, r = b.vu_result(s)
+                _, ro = _oracle_vu(oracle, [wants[s]], C)
+                assert rc == 0 and r.as_dict() == of.vu_result_dict(ro), (C, cmap, flags, s)
+            b.close()
+
+
 def test_peak_tie_breaks_across_lanes_waves_chunks_and_launches(gpu, oracle):
     """first max-|x| in interleaved order wins, also when the candidates sit in
     different lanes, waves, wave-chunks or launches (ref: src/vumeter.c:163-168)"""
