@@ -111,6 +111,7 @@ struct cmhip_batch {
     std::vector<uint16_t> h_gain;          // [S][16]
     bool param_dirty;
     bool all_identity;                     // no stream has a channel map (recomputed on upload)
+    bool all_gain_identity;                // no stream has a gain (same)
     std::vector<EqParam> h_eq;
     unsigned int nsec;
     bool eq_dirty;
@@ -399,6 +400,7 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->parity = 0;
     b->param_dirty = true;
     b->all_identity = true;
+    b->all_gain_identity = true;
     b->eq_dirty = false;
     b->nsec = 0;
     b->timing = false;
@@ -797,6 +799,10 @@ static int flush_params(cmhip_batch_t *b)
         for (const auto &p : b->h_param)
             if (!p.map_identity)
                 b->all_identity = false;
+        b->all_gain_identity = true;
+        for (const auto &q : b->h_gshort)
+            if (q.mode != GAIN_IDENTITY)
+                b->all_gain_identity = false;
         HIP_TRY(hipMemcpyAsync(b->d_param, b->h_param.data(), b->h_param.size() * sizeof(StreamParam),
                                hipMemcpyHostToDevice, b->stream));
         HIP_TRY(hipMemcpyAsync(b->d_gshort, b->h_gshort.data(), b->h_gshort.size() * sizeof(GainShort),
@@ -890,6 +896,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.plane = b->plane;
         a.chunks = 0;                      // the launcher sizes the tiles per kernel variant
         a.identity_maps = b->all_identity ? 1u : 0u;
+        a.identity_gains = b->all_gain_identity ? 1u : 0u;
         a.parity = b->parity;
         HIP_TRY(launch_run(a, b->stream));
         b->in_flight = true;

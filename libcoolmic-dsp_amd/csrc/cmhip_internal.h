@@ -82,6 +82,7 @@ struct RunArgs {
     uint32_t       chunks;         // 4 KiB tiles (one wave each) per stream slot
     uint32_t       parity;         // which VuState::samples slot is current
     uint32_t       identity_maps;  // 1 when no stream of the batch has a channel map
+    uint32_t       identity_gains; // 1 when no stream of the batch has a gain (disabled or unity everywhere)
 };
 
 struct EqArgs {

@@ -306,7 +306,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
 // accumulators live in registers.  NS = min(C, 8) accumulator slots per lane: the half h of
 // dword i feeds slot 2*(i % (NS/2)) + h.
 
-template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U>
+// IDENT: no stream of the batch has a gain (the transform as the reference creates it) -- the
+// magnitudes are the samples' own; instantiated for the read-only runs, which the VALU binds.
+template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U, bool IDENT = false>
 __global__ __launch_bounds__(64) void k_run_wide(RunArgs a)
 {
     constexpr u32 TILE_U = U;
@@ -390,7 +392,10 @@ __global__ __launch_bounds__(64) void k_run_wide(RunArgs a)
             constexpr u32 dummy = 0;
             (void)dummy;
             const u32 g = i % NG;
-            qw[u][i] = gain2(x[u][i], g2[2 * g], g2[2 * g + 1], magic, shift, o[i]);
+            if constexpr (IDENT)
+                qw[u][i] = gain2_identity(x[u][i], o[i]);
+            else
+                qw[u][i] = gain2(x[u][i], g2[2 * g], g2[2 * g + 1], magic, shift, o[i]);
             if constexpr (DO_VU) {
                 vmax[g] = pk_max(vmax[g], qw[u][i]);
                 pw[2 * g].add_lo(qw[u][i]);
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(64) void k_run_wide(RunArgs a)
 
 // STAGE: planar floats go through LDS so that every plane leaves in whole runs (any count but 16,
 // where lanes of equal parity already hold consecutive frames of the same eight channels).
-template <bool WRITE_PCM, bool WRITE_F32, bool DO_VU, bool MAP, bool STAGE>
+template <bool WRITE_PCM, bool WRITE_F32, bool DO_VU, bool MAP, bool STAGE, bool IDENT = false>
 __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_tile)
 {
     constexpr u32 UR = 4;                        // rows in flight
@@ -627,7 +632,8 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
             const u32 tag = (0x7fffu - (r0 + u)) << 1;
 #pragma unroll
             for (u32 i = 0; i < 4; i++) {
-                const u32 qw = gain2(x[u][i], g2[2 * i], g2[2 * i + 1], magic, shift, o[i]);
+                const u32 qw = IDENT ? gain2_identity(x[u][i], o[i])
+                                     : gain2(x[u][i], g2[2 * i], g2[2 * i + 1], magic, shift, o[i]);
                 if constexpr (DO_VU) {
                     best[2 * i] = max(best[2 * i], (qw << 16) | tag | ((x[u][i] >> 15) & 1u));
                     best[2 * i + 1] = max(best[2 * i + 1], (qw & 0xffff0000u) | tag | (x[u][i] >> 31));
@@ -800,6 +806,8 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
 #define CMHIP_WIDE_C(C)                                                            \
     do {                                                                           \
         if (pcm && !f32 && vu) CMHIP_WIDE(C, true, false, true);                   \
+        else if (!pcm && !f32 && vu && a.identity_gains)                           \
+            hipLaunchKernelGGL((k_run_wide<C, false, false, true, 16, true>), dim3(grid), dim3(64), 0, st, b); \
         else if (!pcm && !f32 && vu) CMHIP_WIDE(C, false, false, true);            \
         else if (pcm && !f32 && !vu) CMHIP_WIDE(C, true, false, false);            \
         else if (pcm && f32 && vu) CMHIP_WIDE(C, true, true, true);                \
@@ -851,6 +859,10 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
             hipLaunchKernelGGL((k_run_rows<P_, F_, V_, true, false>), dim3(grid), dim3(64), 0, st, b, W, rpt);  \
     } while (0)
         if (pcm && !f32 && vu) CMHIP_ROWS(true, false, true);
+        else if (!pcm && !f32 && vu && a.identity_gains && a.identity_maps)
+            hipLaunchKernelGGL((k_run_rows<false, false, true, false, false, true>), dim3(grid), dim3(64), 0, st, b, W, rpt);
+        else if (!pcm && !f32 && vu && a.identity_gains)
+            hipLaunchKernelGGL((k_run_rows<false, false, true, true, false, true>), dim3(grid), dim3(64), 0, st, b, W, rpt);
         else if (!pcm && !f32 && vu) CMHIP_ROWS(false, false, true);
         else if (pcm && !f32 && !vu) CMHIP_ROWS(true, false, false);
         else if (pcm && f32 && vu) CMHIP_ROWS(true, true, true);

@@ -298,6 +298,53 @@ def test_short_gain_forms_of_the_read_only_runs(gpu, oracle, C):
             b.close()
 
 
+@pytest.mark.parametrize("C", [3, 4, 6, 8, 13, 16])
+def test_many_channel_read_only_runs_without_gain(gpu, oracle, C):
+    """A batch in which no stream has a gain (the transform as the reference creates it, or unity
+    everywhere) and only the VU window is asked for runs the many-channel kernels without the gain
+    arithmetic; with and without channel maps, two launches per window, ragged lengths."""
+    cm = gpu
+    rng = np.random.default_rng(700 + C)
+    S, T = 5, 9001
+    xs = []
+    for s in range(S):
+        x = _rand_pcm(rng, T * C, "full" if s % 2 == 0 else "edges")
+        x[:3] = [-32768, 32767, -32768]
+        xs.append(x)
+    lens = [T, T - 1, 4097, 17, T]
+    for mapped in (False, True):
+        cmaps = [[int(v) for v in rng.integers(0, C, C)] if mapped and s != 1 else None for s in range(S)]
+        b = cm.Batch(S, C, T, flags=cm.VU)
+        for s in range(S):
+            if s == 2:
+                assert b.set_gain(s, C, 777, [777] * C) == 0      # unity: still no gain
+            if cmaps[s] is not None:
+                assert b.set_chmap(s, cmaps[s]) == 0
+        for lo_f, hi_f in ((0.0, 0.4), (0.4, 1.0)):
+            nfr = []
+            for s in range(S):
+                lo, hi = int(lens[s] * lo_f), int(lens[s] * hi_f)
+                b.upload(s, xs[s][lo * C:hi * C])
+                nfr.append(hi - lo)
+            b.run(max(nfr), frames_per_stream=nfr)
+        for s in range(S):
+            want = _oracle_block(oracle, xs[s][:lens[s] * C], C, None, cmaps[s])
+            rc, r = b.vu_result(s)
+            _, ro = _oracle_vu(oracle, [want], C)
+            assert rc == 0 and r.as_dict() == of.vu_result_dict(ro), (C, mapped, s)
+        # one stream gets a real gain: the whole batch is back on the general kernels
+        assert b.set_gain(0, 1, 1000, [1500]) == 0
+        for s in range(S):
+            b.upload(s, xs[s][:lens[s] * C])
+        b.run(T, frames_per_stream=lens)
+        for s in range(S):
+            want = _oracle_block(oracle, xs[s][:lens[s] * C], C, (1, 1000, [1500]) if s == 0 else None, cmaps[s])
+            rc, r = b.vu_result(s)
+            _, ro = _oracle_vu(oracle, [want], C)
+            assert rc == 0 and r.as_dict() == of.vu_result_dict(ro), (C, mapped, s, "general")
+        b.close()
+
+
 def test_peak_tie_breaks_across_lanes_waves_chunks_and_launches(gpu, oracle):
     """first max-|x| in interleaved order wins, also when the candidates sit in
     different lanes, waves, wave-chunks or launches (ref: src/vumeter.c:163-168)"""
