@@ -852,11 +852,9 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         return COOLMIC_ERROR_GENERIC;
 
     const bool vu = (b->d.flags & CMHIP_VU) != 0;
-    EventPair ev{};
-    if (b->timing) {
+    EventPair ev{};                          // timing: the events take the kernel's own start and end
+    if (b->timing)
         ev = take_events(b);
-        HIP_TRY(hipEventRecord(ev.a, b->stream));
-    }
     if ((b->d.flags & CMHIP_EQ) && b->nsec) {        // without sections the plain kernels do the same
         EqArgs a;
         memset(&a, 0, sizeof(a));
@@ -877,7 +875,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.dbg = b->d_dbg;
         a.stride = b->stride;
         a.plane = b->plane;
-        HIP_TRY(launch_eq(a, b->stream));
+        HIP_TRY(launch_eq(a, b->stream, ev.a, ev.b));
         b->in_flight = true;
     } else {
         RunArgs a;
@@ -898,13 +896,11 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.identity_maps = b->all_identity ? 1u : 0u;
         a.identity_gains = b->all_gain_identity ? 1u : 0u;
         a.parity = b->parity;
-        HIP_TRY(launch_run(a, b->stream));
+        HIP_TRY(launch_run(a, b->stream, ev.a, ev.b));
         b->in_flight = true;
     }
-    if (b->timing) {
-        HIP_TRY(hipEventRecord(ev.b, b->stream));
+    if (b->timing)
         b->ev_used.push_back(ev);
-    }
     if (vu)
         b->parity ^= 1u;                   // the kernel wrote the other samples slot
     return COOLMIC_ERROR_NONE;

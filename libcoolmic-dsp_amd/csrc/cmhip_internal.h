@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace cmhip {
@@ -115,8 +116,10 @@ struct GenArgs {
 };
 
 // launchers (k_block.hip, k_eq.hip, k_misc.hip)
-hipError_t launch_run(const RunArgs &a, hipStream_t st);
-hipError_t launch_eq(const EqArgs &a, hipStream_t st);
+// (ev_start / ev_stop: optional events that take the kernel's own start and end -- hipExtLaunchKernelGGL
+// stamps them from the dispatch itself, without the extra packets of hipEventRecord around the launch)
+hipError_t launch_run(const RunArgs &a, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+hipError_t launch_eq(const EqArgs &a, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t launch_generate(const GenArgs &a, int mode, hipStream_t st);
 hipError_t launch_node_partial(const VuState *vu, uint32_t streams, uint32_t channels,
                                uint32_t parity, uint64_t first_global, uint64_t global_step,

@@ -733,7 +733,7 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
 // ---------------------------------------------------------------------------
 // Launcher of the block kernels: by channel count and by what the batch asks for.
 
-hipError_t launch_run(const RunArgs &a, hipStream_t st)
+hipError_t launch_run(const RunArgs &a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const bool pcm = a.out != nullptr, f32 = a.f32 != nullptr, vu = a.vu != nullptr;
     if (a.streams == 0 || a.frames == 0)
@@ -759,9 +759,9 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
             return hipErrorInvalidValue;
         const u32 grid = a.streams * b.chunks;
 #define CMHIP_FAST(C, P, F, V, U)                                                  \
-    hipLaunchKernelGGL((k_run_fast<C, P, F, V, U>), dim3(grid), dim3(64), 0, st, b)
+    hipExtLaunchKernelGGL((k_run_fast<C, P, F, V, U>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b)
 #define CMHIP_FAST_RO(C, U)                                                        \
-    hipLaunchKernelGGL((k_run_fast_ro<C, U>), dim3(grid), dim3(64), 0, st, b)
+    hipExtLaunchKernelGGL((k_run_fast_ro<C, U>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b)
 #define CMHIP_FAST_C(C)                                                            \
     do {                                                                           \
         if (pcm && !f32 && vu) CMHIP_FAST(C, true, false, true, 4);                \
@@ -799,15 +799,15 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
 #define CMHIP_WIDE(C, P, F, V)                                                     \
     do {                                                                           \
         if (wu == 16u)                                                             \
-            hipLaunchKernelGGL((k_run_wide<C, P, F, V, 16>), dim3(grid), dim3(64), 0, st, b); \
+            hipExtLaunchKernelGGL((k_run_wide<C, P, F, V, 16>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b); \
         else                                                                       \
-            hipLaunchKernelGGL((k_run_wide<C, P, F, V, 8>), dim3(grid), dim3(64), 0, st, b);  \
+            hipExtLaunchKernelGGL((k_run_wide<C, P, F, V, 8>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b);  \
     } while (0)
 #define CMHIP_WIDE_C(C)                                                            \
     do {                                                                           \
         if (pcm && !f32 && vu) CMHIP_WIDE(C, true, false, true);                   \
         else if (!pcm && !f32 && vu && a.identity_gains)                           \
-            hipLaunchKernelGGL((k_run_wide<C, false, false, true, 16, true>), dim3(grid), dim3(64), 0, st, b); \
+            hipExtLaunchKernelGGL((k_run_wide<C, false, false, true, 16, true>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b); \
         else if (!pcm && !f32 && vu) CMHIP_WIDE(C, false, false, true);            \
         else if (pcm && !f32 && !vu) CMHIP_WIDE(C, true, false, false);            \
         else if (pcm && f32 && vu) CMHIP_WIDE(C, true, true, true);                \
@@ -850,19 +850,19 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st)
     do {                                                                                            \
         constexpr bool S_ = F_;                        /* staged float planes unless 16 channels */ \
         if (a.identity_maps && (!F_ || a.channels != 16))                                           \
-            hipLaunchKernelGGL((k_run_rows<P_, F_, V_, false, S_>), dim3(grid), dim3(64), 0, st, b, W, rpt); \
+            hipExtLaunchKernelGGL((k_run_rows<P_, F_, V_, false, S_>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b, W, rpt); \
         else if (a.identity_maps)                                                                   \
-            hipLaunchKernelGGL((k_run_rows<P_, F_, V_, false, false>), dim3(grid), dim3(64), 0, st, b, W, rpt); \
+            hipExtLaunchKernelGGL((k_run_rows<P_, F_, V_, false, false>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b, W, rpt); \
         else if (!F_ || a.channels != 16)                                                           \
-            hipLaunchKernelGGL((k_run_rows<P_, F_, V_, true, S_>), dim3(grid), dim3(64), 0, st, b, W, rpt);  \
+            hipExtLaunchKernelGGL((k_run_rows<P_, F_, V_, true, S_>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b, W, rpt);  \
         else                                                                                        \
-            hipLaunchKernelGGL((k_run_rows<P_, F_, V_, true, false>), dim3(grid), dim3(64), 0, st, b, W, rpt);  \
+            hipExtLaunchKernelGGL((k_run_rows<P_, F_, V_, true, false>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b, W, rpt);  \
     } while (0)
         if (pcm && !f32 && vu) CMHIP_ROWS(true, false, true);
         else if (!pcm && !f32 && vu && a.identity_gains && a.identity_maps)
-            hipLaunchKernelGGL((k_run_rows<false, false, true, false, false, true>), dim3(grid), dim3(64), 0, st, b, W, rpt);
+            hipExtLaunchKernelGGL((k_run_rows<false, false, true, false, false, true>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b, W, rpt);
         else if (!pcm && !f32 && vu && a.identity_gains)
-            hipLaunchKernelGGL((k_run_rows<false, false, true, true, false, true>), dim3(grid), dim3(64), 0, st, b, W, rpt);
+            hipExtLaunchKernelGGL((k_run_rows<false, false, true, true, false, true>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b, W, rpt);
         else if (!pcm && !f32 && vu) CMHIP_ROWS(false, false, true);
         else if (pcm && !f32 && !vu) CMHIP_ROWS(true, false, false);
         else if (pcm && f32 && vu) CMHIP_ROWS(true, true, true);

@@ -20,11 +20,11 @@ coef = np.concatenate([cm.eq3(), cm.design_biquad(1, 48000.0, 3000.0, 4.0, 2.0)]
 b.set_eq(-1, coef)
 b.set_gain(-1, 1, 1000, [900])
 b.generate(cm.GEN_NOISE, 12345, T)
-for _ in range(3):
+for _ in range(100):      # the chip needs ~100 ms of load to reach its clocks (20 launches: 0.88 ms, 1000: 0.78)
     b.run(T)
 b.sync()
 b.timing(True)
-for _ in range(20):
+for _ in range(100):
     b.run(T)
 b.sync()
 ms, n = b.timing_read()

@@ -21,11 +21,11 @@ for C in (1, 2, 6):
           if gain:
               b.set_gain(-1, 1, 1000, [900])
           b.generate(cm.GEN_NOISE, 12345, T)
-          for _ in range(3):
+          for _ in range(60):       # warm: the clocks ramp over the first ~100 ms
               b.run(T)
           b.sync()
           b.timing(True)
-          for _ in range(10):
+          for _ in range(60):
               b.run(T)
           b.sync()
           ms, n = b.timing_read()

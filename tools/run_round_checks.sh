@@ -11,9 +11,9 @@ timeout -k 10 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/
 cat gpurun_out/bench_default.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_c3 $R/gpurun_out/prof_c2
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3 -- python3 $R/bench.py --workload c3 --steps 20 --warmup 3 --no-cpu --no-extras > $R/gpurun_out/c3_rocprof.json 2> $R/gpurun_out/c3_rocprof.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3 -- python3 $R/bench.py --workload c3 --steps 100 --warmup 100 --no-cpu --no-extras > $R/gpurun_out/c3_rocprof.json 2> $R/gpurun_out/c3_rocprof.err
 cat $R/gpurun_out/c3_rocprof.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-extras > $R/gpurun_out/c2_rocprof.json 2> $R/gpurun_out/c2_rocprof.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2 -- python3 $R/bench.py --steps 100 --warmup 100 --no-cpu --no-extras > $R/gpurun_out/c2_rocprof.json 2> $R/gpurun_out/c2_rocprof.err
 cat $R/gpurun_out/c2_rocprof.json
 cd $R
 timeout -k 10 300 bash tools/hbm_pmc.sh c2 > gpurun_out/hbm_c2.log 2>&1 && tail -8 gpurun_out/hbm_c2.log
