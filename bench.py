@@ -47,8 +47,10 @@ WORKLOADS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)     # 100 x 0.37 ms: long enough to average host noise
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: 0.1 s of warm-up and 0.35 s of timed steps -- the chip needs ~100 ms of load to reach the
+    # clocks it then holds (config 2: 0.355 ms per step over 100 steps from idle, 0.349 over 1000)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="override frames per launch")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
@@ -333,12 +335,12 @@ def main():
         else:
             v.set_gain(-1, 1, 1000, [900])
         v.generate(cm.GEN_NOISE, 12345, T, first_global=rank, global_step=world)
-        for _ in range(3):
+        for _ in range(100):
             v.run(T)
         v.sync()
         v.timing(True)
         v.timing_read()
-        for _ in range(30):
+        for _ in range(100):
             v.run(T)
         ms, n = v.timing_read()
         v.close()
@@ -356,12 +358,12 @@ def main():
             if args.workload == "c2":
                 v.set_chmap(-1, [1, 0])
             v.generate(cm.GEN_NOISE, 12345, T, first_global=rank, global_step=world)
-            for _ in range(3):
+            for _ in range(100):
                 v.run(T)
             v.sync()
             v.timing(True)
             v.timing_read()
-            for _ in range(30):
+            for _ in range(100):
                 v.run(T)
             ms, n = v.timing_read()
             v.close()
@@ -382,12 +384,12 @@ def main():
                 if eqz:
                     o.set_eq(-1, cm.eq3(48000.0))
                 o.generate(cm.GEN_NOISE, 12345, t_)
-                for _ in range(3):
+                for _ in range(100):                 # ~0.1 s: the clocks the chip then holds
                     o.run(t_)
                 o.sync()
                 o.timing(True)
                 o.timing_read()
-                for _ in range(20):
+                for _ in range(100):
                     o.run(t_)
                 ms, n = o.timing_read()
                 o.close()
