@@ -224,7 +224,15 @@ void k_eq_pipe(EqArgs a)
     u32 f_r[PASSES];                                      // T-ff: row of pass p
 #pragma unroll
     for (u32 p = 0; p < PASSES; p++) {
-        f_r[p] = (G / 2u) * tw + 8u * p + lane / 8u;
+        // Which rows the eight lane groups of a pass take decides the bank conflicts of their b128 reads:
+        // the hardware serves lanes {0-3,12-15,20-27}, {4-11,16-19,28-31} (and the same + 32) together,
+        // i.e. chunks 0-3 of the first and fourth group with chunks 4-7 of the second and third.  With
+        // rows r, r+16, r+17, r+1 in those four groups the sixteen 16-byte columns are all different
+        // (rows 68 floats apart: a row shifts the columns by one); with r, r+1, r+2, r+3 two collide.
+        {
+            const u32 q = lane / 8u, blk = 2u * tw + p, sub = q & 3u;
+            f_r[p] = 4u * blk + 2u * (q >> 2) + (sub >> 1) + ((sub == 1u || sub == 2u) ? 16u : 0u);
+        }
         if (is_tff) {
             u32 fch;
             const u32 fs = row_stream(f_r[p], fch);
@@ -499,6 +507,12 @@ void k_eq_pipe(EqArgs a)
     };
     // S wave: per row slot i (rows RPI*i + lane/16) the VU window of the int16 result
     static_assert(RPI == 4, "a row slot is four rows");
+    // (rows of a slot: r, r+16, r+1, r+17 for the four lane groups of 16 -- the two groups a b128
+    // read serves together then sit 16 rows apart and their columns do not collide)
+    auto s_row = [&](u32 i) -> u32 {
+        const u32 g4 = lane / SPR;                        // lane group of 16
+        return 2u * (s_first + i) + (g4 >> 1) + ((g4 & 1u) ? 16u : 0u);
+    };
     u64 vpw[NSL], vky[NSL], vbase[NSL];
     u32 vmag[NSL], vidx[NSL];                             // running peak: magnitude, frame << 1 | negative
     u32 v_stream[NSL], v_ch[NSL];                         // stream (or none) and channel of the slot's row
@@ -506,7 +520,7 @@ void k_eq_pipe(EqArgs a)
     for (u32 i = 0; i < NSL; i++) {
         vpw[i] = vky[i] = vbase[i] = 0;
         vmag[i] = vidx[i] = 0;
-        const u32 r = RPI * (s_first + i) + lane / SPR;
+        const u32 r = s_row(i);
         v_stream[i] = row_stream(r, v_ch[i]);
         if (v_stream[i] >= a.streams || i >= s_cnt)
             v_stream[i] = 0xffffffffu;
@@ -527,7 +541,7 @@ void k_eq_pipe(EqArgs a)
                 u32 nin[NSL];                                 // one latency, not one per row slot
 #pragma unroll
                 for (u32 i = 0; i < NSL; i++) {
-                    const u32 r = min(RPI * (s_first + i) + lane / SPR, (u32)G - 1u);   // (slots past s_cnt are skipped below)
+                    const u32 r = min(s_row(i), (u32)G - 1u);   // (slots past s_cnt are skipped below)
                     nin[i] = nfr_lds[r];
                     vin[i] = *reinterpret_cast<const float4 *>(Y + r * EP_ROW + t4);
                 }
@@ -575,14 +589,14 @@ void k_eq_pipe(EqArgs a)
                                         d16[j] = (int16_t)q[j];
                                 }
                             } else if constexpr (STEREO) {
-                                // The two rows of a stream are 16 lanes apart: swap halves with the
-                                // partner (v_permlane16_swap) so that the left row's lanes hold
+                                // The two rows of a stream are 32 lanes apart (s_row): swap halves with the
+                                // partner (v_permlane32_swap) so that the left row's lanes hold
                                 // frames f0, f0+1 of both channels and the right row's lanes frames
                                 // f0+2, f0+3 -- whole interleaved frames, 8 bytes per lane.
                                 const u32 p01 = ((u32)q[0] & 0xffffu) | ((u32)q[1] << 16);
                                 const u32 p23 = ((u32)q[2] & 0xffffu) | ((u32)q[3] << 16);
                                 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
-                                const u32x2 sw2 = __builtin_amdgcn_permlane16_swap(p01, p23, false, false);
+                                const u32x2 sw2 = __builtin_amdgcn_permlane32_swap(p01, p23, false, false);
                                 const u32 left = sw2.x, right = sw2.y;   // this frame pair: channel 0, channel 1
                                 const u32 d0 = __builtin_amdgcn_perm(right, left, 0x05040100u);
                                 const u32 d1 = __builtin_amdgcn_perm(right, left, 0x07060302u);
@@ -671,7 +685,7 @@ void k_eq_pipe(EqArgs a)
                 const u64 ok = (u64)__shfl_xor((long long)ky, o, 64);
                 ky = ok > ky ? ok : ky;
             }
-            const u32 r = RPI * (s_first + i) + lane / SPR;
+            const u32 r = s_row(i);
             if (lane % SPR == 0 && v_stream[i] != 0xffffffffu) {
                 VuState *vs = a.vu + v_stream[i];
                 if (v_ch[i] == 0)
