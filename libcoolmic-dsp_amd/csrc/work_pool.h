@@ -4,6 +4,8 @@
 #define CMHIP_WORK_POOL_H
 
 #include <atomic>
+#include <chrono>
+#include <stdlib.h>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -16,11 +18,17 @@ struct WorkPool {
     // Work is handed out in chunks of `chunk` items from a shared counter and the calling thread
     // works too, so a helper that the OS does not schedule in time (busy hosts, CPU quotas) costs
     // nothing: whoever runs takes the chunks.
+    // Helpers that have just worked wait for the next job in a short spin before they go to sleep
+    // (default 400 us, $CMHIP_POOL_SPIN_US): jobs that come every few hundred microseconds -- a
+    // bench loop, a busy streaming host -- then never pay a futex wake-up, which on a loaded host
+    // took longer than the job (a step of 0.35 ms grew to 0.40-0.46 ms).
     unsigned chunk = 64;
     std::vector<std::thread> workers;
     std::mutex m;
     std::condition_variable cv_work, cv_done;
-    unsigned generation = 0, active = 0;
+    std::atomic<unsigned> generation{0}, active{0};
+    unsigned sleepers = 0;                            // helpers inside cv_work.wait (under m)
+    unsigned spin_us = 400;
     bool stop = false;
     void (*fn)(void *, unsigned, unsigned) = nullptr;
     void *arg = nullptr;
@@ -29,6 +37,8 @@ struct WorkPool {
 
     explicit WorkPool(unsigned n)
     {
+        if (const char *e = getenv("CMHIP_POOL_SPIN_US"))
+            spin_us = (unsigned)atoi(e);
         for (unsigned i = 0; i < n; i++)
             workers.emplace_back([this] { loop(); });
     }
@@ -37,6 +47,7 @@ struct WorkPool {
         {
             std::lock_guard<std::mutex> g(m);
             stop = true;
+            generation.fetch_add(1, std::memory_order_release);   // spinning helpers look at this
         }
         cv_work.notify_all();
         for (auto &t : workers)
@@ -51,34 +62,60 @@ struct WorkPool {
             f(a, lo, lo + chunk < tot ? lo + chunk : tot);
         }
     }
+    // spins until pred() or `us` microseconds have passed; true if pred() held
+    template <typename P>
+    static bool spin_for(unsigned us, P pred)
+    {
+        if (pred())
+            return true;
+        if (!us)
+            return false;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            for (int i = 0; i < 64; i++) {
+                if (pred())
+                    return true;
+                __builtin_ia32_pause();
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(us))
+                return pred();
+        }
+    }
     void loop()
     {
         unsigned seen = 0;
+        bool worked = false;                          // only a helper that has just worked spins
         for (;;) {
             void (*f)(void *, unsigned, unsigned);
             void *a;
             unsigned tot;
-            {
+            if (!(worked && spin_for(spin_us, [&] { return generation.load(std::memory_order_acquire) != seen; }))) {
                 std::unique_lock<std::mutex> g(m);
-                cv_work.wait(g, [&] { return stop || generation != seen; });
+                sleepers++;
+                cv_work.wait(g, [&] { return stop || generation.load(std::memory_order_relaxed) != seen; });
+                sleepers--;
+            }
+            {
+                std::lock_guard<std::mutex> g(m);     // the job's fields and `next` belong together
                 if (stop)
                     return;
-                seen = generation;
+                seen = generation.load(std::memory_order_relaxed);
                 f = fn;
                 a = arg;
                 tot = total;
-                active++;
+                active.fetch_add(1, std::memory_order_relaxed);
             }
             drain(f, a, tot);
-            {
+            worked = true;
+            if (active.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 std::lock_guard<std::mutex> g(m);
-                if (--active == 0)
-                    cv_done.notify_one();
+                cv_done.notify_one();
             }
         }
     }
     void run(void (*f)(void *, unsigned, unsigned), void *a, unsigned tot, unsigned per_chunk = 64)
     {
+        bool wake;
         {
             std::lock_guard<std::mutex> g(m);
             chunk = per_chunk ? per_chunk : 1;
@@ -86,12 +123,17 @@ struct WorkPool {
             arg = a;
             total = tot;
             next.store(0, std::memory_order_relaxed);
-            generation++;
+            generation.fetch_add(1, std::memory_order_release);
+            wake = sleepers != 0;
         }
-        cv_work.notify_all();
+        if (wake)
+            cv_work.notify_all();
         drain(f, a, tot);                             // the caller works as well
-        std::unique_lock<std::mutex> g(m);            // chunks taken by helpers may still be running
-        cv_done.wait(g, [&] { return active == 0; });
+        // chunks taken by helpers may still be running: they are short, so look before sleeping
+        if (spin_for(200, [&] { return active.load(std::memory_order_acquire) == 0; }))
+            return;
+        std::unique_lock<std::mutex> g(m);
+        cv_done.wait(g, [&] { return active.load(std::memory_order_acquire) == 0; });
     }
 };
 
