@@ -30,19 +30,19 @@ __device__ __forceinline__ int f32_to_i16(float y)
 // which is the oracle's Direct Form I in the same operation order.  A workgroup owns G
 // rows (a row = one channel of one stream) and walks them in 64-frame blocks, one
 // __syncthreads() per block, with waves of four roles that hand 64-frame rows to each other
-// through double-buffered LDS tiles:
+// through double-buffered LDS tiles (F_k of block b is written in step b+2k, Y_k in step b+2k+1,
+// the block leaves in step b+2*NSEC):
 //
 //   T-in waves (lane = row x 8-frame chunk; time-parallel, G/8 of them):
 //     global load (two blocks ahead) -> gain -> float -> feed-forward of section 0 -> F_0
-//   T-ff waves (same lane shape, G/2 rows each in passes of 8 rows):
+//   T-ff waves (same lane shape, G/2 rows each in passes of 8 rows -- which rows: see f_r below):
 //     Y_k-1 -> feed-forward of section k -> F_k               (k = 1 .. NSEC-1)
 //     x[t-1], x[t-2] of a chunk come from the neighbouring lane by DPP (row_shr:1), those
 //     of a block's first chunk from the last chunk of the previous step (row_shl:7).
 //   R waves (lane = section x row; 64/G sections side by side, sequential in time):
-//     F_k (loaded into registers a step ahead) -> the two dependent FMAs per sample -> Y_k
-//   S work: Y_last -> coalesced non-temporal global stores (float planes), and for an int16
-//     result / VU window the conversion and the window of it; dealt out over R and T-ff waves
-//     (float planes only) or done by S waves of their own -- see eq_role() below.
+//     F_k (16 ds_read_b128) -> the two dependent FMAs per sample -> Y_k (16 ds_write_b128)
+//   S waves (four; lane = row x 4-frame piece): Y_last -> coalesced non-temporal global stores
+//     (float planes), and for an int16 result / VU window the conversion and the window of it.
 //
 // Measured on MI355X (tools/ubench_chain.hip, ubench_lds*.hip): a wave alone issues one
 // VALU op per ~4.3 clk, a dependent one after ~8; ds_read_b128 costs a wave ~5-10 clk to
