@@ -100,6 +100,12 @@ struct WorkPool {
                 if (stop)
                     return;
                 seen = generation.load(std::memory_order_relaxed);
+                // A helper that comes late finds every chunk taken: it must not join (the caller may
+                // already have returned, and the next job will reset `next` under this lock -- a helper
+                // still holding this job's bounds would then take chunks of the next one and drop them).
+                // While chunks are left the caller is still inside run(), and it will see `active`.
+                if (next.load(std::memory_order_relaxed) >= total)
+                    continue;
                 f = fn;
                 a = arg;
                 tot = total;
@@ -129,9 +135,10 @@ struct WorkPool {
         if (wake)
             cv_work.notify_all();
         drain(f, a, tot);                             // the caller works as well
-        // chunks taken by helpers may still be running: they are short, so look before sleeping
-        if (spin_for(200, [&] { return active.load(std::memory_order_acquire) == 0; }))
-            return;
+        // chunks taken by helpers may still be running: they are short, so look before sleeping.
+        // The last look is under the lock: a helper may be between finding chunks left and counting
+        // itself in (it holds the lock there), and must be waited for like the others.
+        spin_for(200, [&] { return active.load(std::memory_order_acquire) == 0; });
         std::unique_lock<std::mutex> g(m);
         cv_done.wait(g, [&] { return active.load(std::memory_order_acquire) == 0; });
     }
