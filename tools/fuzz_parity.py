@@ -43,10 +43,16 @@ for case in range(cases):
     any_map = rng.random() < 0.5
     b = cm.Batch(S, C, T, flags=flags)
     gas, maps = [], []
+    whole = rng.random()                     # some batches: no gain anywhere / every gain below its scale
     for s in range(S):
         mode = int(rng.integers(0, 4))
         ga = None if mode == 0 else (C, int(rng.integers(1, 65536)), [int(v) for v in rng.integers(0, 65536, C)]) \
             if mode < 3 else (1, int(rng.choice([1, 1000, 65535])), [int(rng.integers(0, 65536))])
+        if whole < 0.15:
+            ga = None if rng.random() < 0.7 else (C, 4242, [4242] * C)              # disabled or unity
+        elif whole < 0.3:
+            sc = int(rng.integers(2, 65536))
+            ga = (C, sc, [int(v) for v in rng.integers(0, sc, C)])                  # all below the scale
         m = [int(v) for v in rng.integers(0, C, C)] if any_map and rng.random() < 0.7 else None
         if ga:
             assert b.set_gain(s, *ga) == 0
