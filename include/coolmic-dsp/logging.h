@@ -21,12 +21,13 @@ typedef enum coolmic_logging_level {
     COOLMIC_LOGGING_LEVEL_DEBUG
 } coolmic_logging_level_t;
 
-/* "FATAL", "ERROR", ... as they appear in a formatted line; "UNKNOWN" for anything else */
+/* "FATAL", "ERROR", ... as they appear in a formatted line; "(unknown)" for anything else */
 const char *coolmic_logging_level2string(coolmic_logging_level_t level);
 
 /* Formats one line and hands it to the callback.  `error` is a COOLMIC_ERROR_* code whose text is
  * appended, or COOLMIC_ERROR_NONE.  Callable from any thread; returns COOLMIC_ERROR_NONE, also when
- * no callback is installed.  Use the coolmic_logging_log() macro: it supplies file, line and the
+ * no callback is installed (COOLMIC_ERROR_FAULT without a format, COOLMIC_ERROR_NOMEM if a line cannot
+ * be built).  Use the coolmic_logging_log() macro: it supplies file, line and the
  * COOLMIC_COMPONENT string that every translation unit defines before including this header. */
 int coolmic_logging_log_real(const char *file, unsigned long int line, const char *component,
                              coolmic_logging_level_t level, int error, const char *format, ...)
