@@ -835,7 +835,10 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st, hipEvent_t ev_start, hip
         const u32 W = 64u - 64u % P;
         // rows per tile (~1 KiB each); with 4 or 8 channels (here only when they carry channel
         // maps) every lane adds to the same few LDS words at the end: bigger tiles, fewer merges
-        u32 rpt = P == 1 ? 32u : (!pcm && !f32) ? 16u : 8u;
+        // (at sustained clocks, tools/bench_generic.py: runs with channel maps gain 3-5 % from 16 rows
+        // instead of 8, 16 channels writing PCM 4-16 % from 16 instead of 32)
+        const bool ro = !pcm && !f32;
+        u32 rpt = P == 1 ? ((a.channels == 16 && !ro) ? 16u : 32u) : ro ? 16u : (a.identity_maps ? 8u : 16u);
         if (const char *e = getenv("CMHIP_ROWS_RPT"))          // tuning knob (tools/bench_generic.py)
             rpt = (u32)atoi(e) ? (u32)atoi(e) : rpt;
         const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;

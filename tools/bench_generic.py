@@ -18,12 +18,12 @@ for C in (3, 5, 6, 7, 12, 15, 4, 8, 16):
         if mapped:
             b.set_chmap(-1, [(c + 1) % C for c in range(C)])
         b.generate(cm.GEN_NOISE, 1, T)
-        for _ in range(2):
+        for _ in range(300):                   # ~0.1 s: the clocks the chip then holds
             b.run(T)
         b.sync()
         b.timing(True)
         b.timing_read()
-        for _ in range(5):
+        for _ in range(100):
             b.run(T)
         ms, n = b.timing_read()
         gbs = S * C * T * bps / (ms / n * 1e-3) / 1e9
