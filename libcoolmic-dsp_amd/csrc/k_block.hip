@@ -22,7 +22,7 @@ namespace cmhip {
 
 // read-only runs take bigger tiles to amortise the epilogue (picked per channel count from
 // interleaved A/B runs, tools/ab_tiles.py); $CMHIP_VU_TILE (4, 8, 16) overrides for tuning
-constexpr u32 TILE_U_VUONLY_MONO = 8;
+constexpr u32 TILE_U_VUONLY_MONO = 16;         // (8 until the A/B was repeated at sustained clocks: 6.03 -> 6.51 TB/s)
 constexpr u32 TILE_U_VUONLY_STEREO = 16;
 
 // One wave = one 4 KiB tile of one stream, one pass: four non-temporal 16-byte loads per
