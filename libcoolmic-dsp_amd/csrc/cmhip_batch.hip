@@ -96,6 +96,11 @@ struct cmhip_batch {
     unsigned int cur;
     hipStream_t copy_stream;               // snapshots travel here, beside the next run
     hipEvent_t ev_main, ev_reset[3];
+    // The end of the last run as its own dispatch stamped it (hipExtLaunchKernelGGL): what a snapshot
+    // makes the copy stream wait for instead of an event recorded behind the kernel -- one packet less
+    // on the main stream per step.  nullptr once anything else on the main stream touched the windows.
+    hipEvent_t ev_done[4], last_done;
+    unsigned done_next;
     bool reset_pending[3];
     struct WorkPool *pool;
     uint32_t *d_nframes;
@@ -224,6 +229,9 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     delete b->pool;
     if (b->ev_main)
         (void)hipEventDestroy(b->ev_main);
+    for (int i = 0; i < 4; i++)
+        if (b->ev_done[i])
+            (void)hipEventDestroy(b->ev_done[i]);
     for (int i = 0; i < 3; i++)
         if (b->ev_reset[i])
             (void)hipEventDestroy(b->ev_reset[i]);
@@ -307,6 +315,8 @@ static int batch_init(cmhip_batch_t *b)
     b->d_vu = b->d_vu2[0];
     HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
+    for (int i = 0; i < 4; i++)
+        HIP_TRY(hipEventCreate(&b->ev_done[i]));
     HIP_TRY(hipMalloc((void **)&b->d_nframes, S * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&b->d_sink, sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(b->d_sink, 0, sizeof(unsigned long long), b->stream));
@@ -379,6 +389,9 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->cur = 0;
     b->copy_stream = nullptr;
     b->ev_main = nullptr;
+    b->ev_done[0] = b->ev_done[1] = b->ev_done[2] = b->ev_done[3] = nullptr;
+    b->last_done = nullptr;
+    b->done_next = 0;
     b->ev_reset[0] = b->ev_reset[1] = b->ev_reset[2] = nullptr;
     b->reset_pending[0] = b->reset_pending[1] = b->reset_pending[2] = false;
     b->pool = nullptr;
@@ -853,8 +866,13 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
 
     const bool vu = (b->d.flags & CMHIP_VU) != 0;
     EventPair ev{};                          // timing: the events take the kernel's own start and end
-    if (b->timing)
+    if (b->timing) {
         ev = take_events(b);
+    } else if (vu) {                         // the end of this run, for the next snapshot
+        ev.b = b->ev_done[b->done_next];
+        b->done_next = (b->done_next + 1u) & 3u;
+    }
+    b->last_done = vu ? ev.b : nullptr;
     if ((b->d.flags & CMHIP_EQ) && b->nsec) {        // without sections the plain kernels do the same
         EqArgs a;
         memset(&a, 0, sizeof(a));
@@ -966,6 +984,7 @@ extern "C" int cmhip_batch_vu_result(cmhip_batch_t *b, unsigned int stream,
         return fail(COOLMIC_ERROR_INVAL, "vu_result: stream out of range or batch without VU");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
+    b->last_done = nullptr;                  // main-stream work on the windows follows the last run
     VuState v;
     HIP_TRY(hipMemcpyAsync(&v, b->d_vu + stream, sizeof(v), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -992,8 +1011,13 @@ extern "C" int cmhip_batch_vu_snapshot(cmhip_batch_t *b)
     // two, every launch waited for the copy + clear that ran beside its predecessor.
     const unsigned i = b->cur;
     const unsigned slot = (b->snap_head + b->snap_count) & 1u;
-    HIP_TRY(hipEventRecord(b->ev_main, b->stream));
-    HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_main, 0));
+    if (b->last_done) {
+        HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->last_done, 0));
+        b->last_done = nullptr;
+    } else {
+        HIP_TRY(hipEventRecord(b->ev_main, b->stream));
+        HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_main, 0));
+    }
     HIP_TRY(hipMemcpyAsync(b->h_snap2[slot], b->d_vu2[i], bytes, hipMemcpyDeviceToHost, b->copy_stream));
     HIP_TRY(hipEventRecord(b->snap_event2[slot], b->copy_stream));
     HIP_TRY(hipMemsetAsync(b->d_vu2[i], 0, bytes, b->copy_stream));
@@ -1002,7 +1026,9 @@ extern "C" int cmhip_batch_vu_snapshot(cmhip_batch_t *b)
     b->cur = (i + 1u) % 3u;
     b->d_vu = b->d_vu2[b->cur];
     if (b->reset_pending[b->cur]) {          // the set we switch to must have been cleared
-        HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_reset[b->cur], 0));
+        // (it was, a launch ago, in the steady state: then the main stream needs no packet for it)
+        if (hipEventQuery(b->ev_reset[b->cur]) != hipSuccess)
+            HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_reset[b->cur], 0));
         b->reset_pending[b->cur] = false;
     }
     b->snap_parity2[slot] = b->parity;
@@ -1066,6 +1092,7 @@ extern "C" int cmhip_batch_vu_reset(cmhip_batch_t *b, long stream)
         return fail(COOLMIC_ERROR_INVAL, "vu_reset: stream %ld out of range", stream);
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
+    b->last_done = nullptr;                  // main-stream work on the windows follows the last run
     if (stream < 0)
         HIP_TRY(hipMemsetAsync(b->d_vu, 0, b->d.streams * sizeof(VuState), b->stream));
     else
@@ -1108,6 +1135,7 @@ extern "C" int cmhip_batch_vu_node_partial(cmhip_batch_t *b, void *dst_device,
         return fail(COOLMIC_ERROR_INVAL, "vu_node_partial: batch without VU");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
+    b->last_done = nullptr;                  // main-stream work on the windows follows the last run
     HIP_TRY(launch_node_partial(b->d_vu, b->d.streams, b->d.channels, b->parity, first_global, global_step,
                                 (long long *)dst_device, b->stream));
     return COOLMIC_ERROR_NONE;
