@@ -14,12 +14,12 @@ for name, S, C in (("stereo", 2048, 2), ("mono", 4096, 1)):
         b = cm.Batch(S, C, T, flags=flags)
         b.set_gain(-1, C, 1000, [750, 1250][:C] if C == 2 else [900])
         b.generate(cm.GEN_NOISE, 1, T)
-        for _ in range(2):
+        for _ in range(300):      # ~0.1 s of load: the clocks the chip then holds
             b.run(T)
         b.sync()
         b.timing(True)
         b.timing_read()
-        for _ in range(8):
+        for _ in range(100):
             b.run(T)
         ms, n = b.timing_read()
         print(f"{name:6s} S={S} {what:15s} {ms/n:7.3f} ms  {S*C*T*bps/(ms/n*1e-3)/1e9:7.0f} GB/s ({bps} B/sample)")

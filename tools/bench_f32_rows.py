@@ -11,10 +11,10 @@ for C in (3, 4, 6, 8, 16):
         b = cm.Batch(S, C, T, flags=flags)
         b.set_gain(-1, 1, 1000, [900])
         b.generate(cm.GEN_NOISE, 1, T)
-        for _ in range(2):
+        for _ in range(300):      # ~0.1 s of load: the clocks the chip then holds
             b.run(T)
         b.sync(); b.timing(True); b.timing_read()
-        for _ in range(5):
+        for _ in range(100):
             b.run(T)
         ms, n = b.timing_read()
         print(f"C={C:2d} S={S:5d} {name:10s} {ms/n:8.3f} ms  {S*C*T*bps/(ms/n*1e-3)/1e9:7.0f} GB/s")
