@@ -8,12 +8,17 @@ one fused gain(+channel map) -> VU launch over every stream of the rank's shard,
 asynchronous snapshot of all VU windows to the host, and the host-side dB finish
 (double, as the reference) of the previous step's windows, overlapped with the GPU.
 
+One process per GPU.  `python bench.py --gpus N` with N > 1 starts the N rank processes
+itself (before anything touches HIP) and relays rank 0's line; under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks are
+already there (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment).
+
 Workloads (per GPU; stream s of the node lives on rank s % N -- round-robin shards,
 no data-path collective, "weak" scaling):
   c2  4096 stereo streams x 65536 frames, channel swap + gains {750,1250}/1000, PCM
       materialised (2 B read + 2 B written per sample)             [default, configs[1]]
   c4  8192 mono streams x 65536 frames, gain 900/1000, PCM materialised  [configs[3]]
-  c5  c4 + node-global VU: one RCCL all-reduce pair per step             [configs[4]]
+  c5  c4 + node-global VU: RCCL all-reduce of the blocks' records         [configs[4]]
   c3  8192 mono streams, int16 -> float + 3-band EQ, float out           [configs[2]]
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, timed with HIP
@@ -24,6 +29,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MIN_WARMUP_S = 0.15            # the chip reaches the clocks it then holds after ~100 ms of load
 
 WORKLOADS = {
     # name: (streams/GPU, channels, frames, bytes per sample, description)
@@ -38,17 +46,17 @@ WORKLOADS = {
                               "channel swap + gains {750,1250}/1000 -> VU, PCM materialised"),
     "c4": (8192, 1, 65536, 4, "8192 mono int16 streams x 65536 frames per GPU (65536 streams "
                               "round-robin over 8 GPUs), gain 900/1000 -> VU, PCM materialised"),
-    "c5": (8192, 1, 65536, 4, "c4 + node-global VU via RCCL all-reduce each step"),
+    "c5": (8192, 1, 65536, 4, "c4 + node-global VU via RCCL all-reduce of the blocks' records"),
     "c3": (8192, 1, 65536, 6, "8192 mono streams x 65536 frames per GPU, int16 -> float + "
                               "3-band biquad EQ, planar float out"),
 }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 0.1 s of warm-up and 0.35 s of timed steps -- the chip needs ~100 ms of load to reach the
-    # clocks it then holds (config 2: 0.355 ms per step over 100 steps from idle, 0.349 over 1000)
+    # defaults: 0.1 s of warm-up and 0.35 s of timed steps; whatever --warmup says, warm-up
+    # continues until MIN_WARMUP_S of wall time have passed (reported as warmup_ms_effective)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
@@ -58,10 +66,117 @@ def main():
                     help="fixed total: the workload's streams are divided among the ranks (default: "
                          "weak scaling, the workload's streams per GPU)")
     ap.add_argument("--node-batch", type=int, default=8,
-                    help="config 5: blocks whose node-global VU records travel in one all-gather")
+                    help="config 5: blocks whose node-global VU records travel in one all-reduce pair")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-extras", action="store_true", help="skip ceilings / VU-only line")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip ceilings / VU-only line / PCIe line")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """The parent of a self-launched multi-GPU run: N fresh rank processes of this script, one
+    per GPU, started before this process has loaded the engine or touched HIP (nothing is
+    exec'ed from a process that initialised the GPU).  Relays rank 0's JSON line; returns the
+    worst exit code."""
+    env0 = dict(os.environ)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0.setdefault("MASTER_PORT", str(_free_port()))
+    env0["WORLD_SIZE"] = str(n)
+    env0["LOCAL_WORLD_SIZE"] = str(n)
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    line = b""
+    for raw in procs[0].stdout:                 # rank 0 prints exactly one line on stdout
+        if raw.strip():
+            line = raw
+    worst = 0
+    deadline = None
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            rc = p.poll()
+            if rc is None:
+                continue
+            pending.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                if deadline is None:            # a rank died: the others would wait at a barrier for ever
+                    deadline = time.time() + 20.0
+        if deadline is not None and time.time() > deadline:
+            for p in pending:
+                p.kill()                        # exactly the processes started above
+            deadline = time.time() + 1e9
+        time.sleep(0.05)
+    if line:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    elif worst == 0:
+        worst = 1
+    return worst
+
+
+def exchange_node_id(rank, world, make_id):
+    """Config 5: rank 0's 128-byte RCCL id reaches the other ranks over a plain TCP socket next
+    to MASTER_PORT -- before torch is imported, so that the engine and librccl both sit on the
+    system HIP runtime (torch, imported later for gloo only, brings a second one)."""
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    base = int(os.environ.get("MASTER_PORT", "29599"))
+    ports = [base + 101 + 37 * i for i in range(8)]
+    magic = b"cmhip-node-id:"
+    if world == 1:
+        return make_id()
+    if rank == 0:
+        uid = make_id()
+        srv = None
+        for p in ports:
+            try:
+                srv = socket.create_server((addr, p), reuse_port=False)
+                break
+            except OSError:
+                continue
+        if srv is None:
+            raise SystemExit("bench.py: no free port for the node id exchange near MASTER_PORT")
+        srv.settimeout(120)
+        served = 0
+        while served < world - 1:
+            conn, _ = srv.accept()
+            with conn:
+                conn.sendall(magic + uid)
+            served += 1
+        srv.close()
+        return uid
+    want = len(magic) + 128
+    t_end = time.time() + 120
+    while time.time() < t_end:
+        for p in ports:
+            try:
+                with socket.create_connection((addr, p), timeout=2) as c:
+                    buf = b""
+                    while len(buf) < want:
+                        chunk = c.recv(want - len(buf))
+                        if not chunk:
+                            break
+                        buf += chunk
+                if len(buf) == want and buf.startswith(magic):
+                    return buf[len(magic):]
+            except OSError:
+                continue
+        time.sleep(0.1)
+    raise SystemExit("bench.py: rank %d never received the node id" % rank)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
 
     # stdout carries exactly one line, rank 0's JSON: whatever libraries print on the way (gloo
     # announces its connections on stdout) goes to stderr with everything else
@@ -72,58 +187,31 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus %d needs one process per GPU: launch with "
-                     "python -m torch.distributed.run --nproc-per-node %d ..." % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
-    # torch is plumbing for the multi-rank run only (rendezvous, the barrier and the clock over
-    # ranks; RCCL for the one workload with an exchange step, config 5).  It brings its own HIP
-    # runtime (ROCm 7.0 inside the wheel), and under that runtime's default direct dispatch the
-    # submitting thread of this step loop was seen stalling for a kernel's length per step on
-    # busy hosts (0.7 ms per step instead of 0.37).  So:
-    #   * one rank: torch is not loaded at all;
-    #   * several ranks without a data-path collective (c2, c3, c4): the engine is loaded FIRST
-    #     and keeps the system HIP runtime, torch comes second and only runs gloo on the CPU for
-    #     the barrier and the max-over-ranks clock -- torch.cuda is never touched;
-    #   * config 5 (node-global VU over RCCL): torch first, with AMD_DIRECT_DISPATCH=0 unless the
-    #     environment says otherwise (0.40 ms per step).
-    force_node = os.environ.get("COOLMIC_BENCH_FORCE_NODE") == "1"       # single-rank test of the reduce path
-    # Rehearsal knob for a 1-GPU box (never set by the driver): all ranks share device 0 and any
-    # GPU collective is replaced by gloo on host copies, so the N>1 code can run without N GPUs.
+    # torch is plumbing for the multi-rank run only: rendezvous, the barrier and the clock over
+    # the ranks, all over gloo on the CPU -- torch.cuda is never touched.  It brings its own HIP
+    # runtime (ROCm 7.0 inside the wheel), so the engine (and for config 5 librccl, through
+    # cmhip_node_new) is loaded FIRST and stays on the system runtime; a single rank never loads
+    # torch.  The one real exchange, config 5's node-global VU, is the engine's own RCCL call.
+    force_node = os.environ.get("COOLMIC_BENCH_FORCE_NODE") == "1"       # single-rank run of the reduce path
+    # Rehearsal knob for a 1-GPU box (never set by the driver): all ranks share device 0; RCCL
+    # refuses two ranks on one GPU, so every rank reduces in a one-rank communicator and the
+    # records are merged over gloo on the host (cmhip_node_merge_host, the "replicas only" form).
     rehearsal = os.environ.get("COOLMIC_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    gpu_torch = args.workload == "c5" and (world > 1 or force_node)    # torch.cuda is needed
-    need_torch = world > 1 or force_node
-    torch = dist = None
-    if gpu_torch:
-        os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
-        import torch
-        import torch.distributed as dist
 
     import __graft_entry__ as ge
     cm = ge.load_package()
     from libcoolmic_dsp_amd import shard
 
+    if os.environ.get("COOLMIC_BENCH_DRYRUN") == "1":
+        # launch plumbing only, for the CPU tests: rendezvous, node-id exchange, barrier, the
+        # max-over-ranks clock, one JSON line from rank 0 -- no GPU work, no throughput
+        return dry_run(args, rank, world, json_fd, shard)
     if cm.device_count() < 1:
         sys.exit("bench.py: no HIP device; this path has no CPU fallback")
-    if need_torch and not gpu_torch:
-        import torch
-        import torch.distributed as dist
-    if need_torch:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29599")
-        if gpu_torch and not rehearsal:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            if gpu_torch:
-                torch.cuda.set_device(local_rank)
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-    coll_device = "cuda" if gpu_torch and not rehearsal else "cpu"
 
     S, Cn, T, bps, desc = WORKLOADS[args.workload]
     if args.frames:
@@ -136,6 +224,24 @@ def main():
         S //= world
     eq = args.workload == "c3"
     node_vu = args.workload == "c5"
+    node_on = node_vu and (world > 1 or force_node)
+    NB = max(1, args.node_batch)
+
+    node = None
+    if node_on:
+        if rehearsal:
+            node = cm.Node(local_rank, 1, 0, cm.node_unique_id(), max_records=NB)
+        else:
+            uid = exchange_node_id(rank, world, cm.node_unique_id)
+            node = cm.Node(local_rank, world, rank, uid, max_records=NB)
+
+    torch = dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29599")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     if eq:
         flags = cm.EQ | cm.OUT_F32
@@ -158,40 +264,19 @@ def main():
     has_vu = bool(flags & cm.VU)
     results = (cm.VuResult * S)()
     rcs = (C.c_int * S)()
-    # node-global VU (config 5): every block leaves one 34-word record per rank; the records of
-    # --node-batch blocks travel in ONE all-gather (the exchange is latency bound) and are combined
-    # on the device.  Two sets of record buffers alternate so that a set's exchange runs beside the
-    # next blocks' kernels; the batch's stream and torch's stream order themselves with events,
-    # the host never waits inside the loop.
-    node_on = node_vu and (world > 1 or force_node)
-    NB = max(1, args.node_batch)
-    node_sets = [torch.zeros(NB, cm.NODE_WORDS, dtype=torch.int64, device="cuda") for _ in range(2)] if node_on else None
-    node_scratch = torch.empty(world, NB, cm.NODE_WORDS, dtype=torch.int64,
-                               device="cpu" if rehearsal else "cuda") if node_on else None
-    node_host = torch.zeros(NB, cm.NODE_WORDS, dtype=torch.int64) if node_on and rehearsal else None
-    ext_stream = torch.cuda.ExternalStream(b.hip_stream()) if node_on and not rehearsal else None
-    ev_ready = [torch.cuda.Event() for _ in range(2)] if ext_stream is not None else None
-    ev_done = [torch.cuda.Event() for _ in range(2)] if ext_stream is not None else None
+    # node-global VU (config 5): every block leaves one 34-word record per rank in a slot of the
+    # node's current record set; the records of --node-batch blocks are reduced over the ranks by
+    # ONE pair of RCCL all-reduces (the exchange is latency bound), on the node's own stream,
+    # beside the next blocks' kernels, which fill the other set.  The host never waits in the loop.
     node_step = [0]
-    node_result = [None]                   # combined records of the last exchanged set
+    node_last = [None]                     # (set, count) of the last exchange
 
-    def node_exchange(k):
-        words = node_sets[k]
-        if ext_stream is None:             # rehearsal (gloo): through a host copy
-            b.sync()
-            node_host.copy_(words)
-            node_result[0] = shard.gather_node_records(dist, node_host, node_scratch)
-        else:
-            ev_ready[k].record(ext_stream)
-            cur = torch.cuda.current_stream()
-            cur.wait_event(ev_ready[k])                # RCCL runs after the records are written
-            node_result[0] = shard.gather_node_records(dist, words, node_scratch)
-            ev_done[k].record(cur)
+    def node_exchange(k, count):
+        node.allreduce(k, count, after=b)
+        node_last[0] = (k, count)
 
     def device_sync():
         cm.device_synchronize(local_rank)       # hipDeviceSynchronize: every stream of this rank's GPU
-        if gpu_torch:
-            torch.cuda.synchronize()
 
     def barrier():
         device_sync()
@@ -213,11 +298,9 @@ def main():
                 i = node_step[0]
                 node_step[0] += 1
                 k, slot = (i // NB) & 1, i % NB
-                if slot == 0 and ext_stream is not None:
-                    ext_stream.wait_event(ev_done[k])      # the exchange that last used this set
-                b.node_partial(node_sets[k][slot].data_ptr(), first_global=rank, global_step=world)
+                node.partial(b, k, slot, first_global=rank, global_step=world)
                 if slot == NB - 1:
-                    node_exchange(k)
+                    node_exchange(k, NB)
             if has_vu:
                 b.vu_snapshot()                      # async D2H of all windows + reset
                 tp2 = time.perf_counter()
@@ -233,13 +316,22 @@ def main():
         if pending:
             b.vu_collect(results, rcs)
         if node_on and node_step[0] % NB:              # records of a partly filled set
-            node_exchange((node_step[0] // NB) & 1)
+            node_exchange((node_step[0] // NB) & 1, node_step[0] % NB)
             node_step[0] += NB - node_step[0] % NB
         b.sync()
-        if node_on and ext_stream is not None:
-            torch.cuda.current_stream().synchronize()
 
+    # warm-up: the steps asked for, then on until MIN_WARMUP_S of wall time have passed, so that a
+    # short run (the driver's --steps 20 --warmup 5) is timed at the clocks the chip then holds
+    t_w = time.perf_counter()
     run_steps(args.warmup)
+    warm_steps = args.warmup
+    chunk = max(8, NB if node_on else 8)
+    while time.perf_counter() - t_w < MIN_WARMUP_S:
+        run_steps(chunk)
+        warm_steps += chunk
+    device_sync()
+    warm_ms = (time.perf_counter() - t_w) * 1e3
+
     b.timing(True)
     b.timing_read()
     barrier()
@@ -251,7 +343,7 @@ def main():
     b.timing(False)
 
     if world > 1:
-        dt = shard.max_over_ranks(dist, dt, device=coll_device)
+        dt = shard.max_over_ranks(dist, dt, device="cpu")
 
     samples_per_step_rank = S * Cn * T
     total_samples = samples_per_step_rank * world * args.steps
@@ -259,30 +351,41 @@ def main():
 
     kern_avg_ms = kern_ms / max(launches, 1)
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
-    traffic = None
-    # HBM bytes per launch from the PMC passes of tools/hbm_pmc.sh, kept per workload
+    # HBM bytes per launch: NOT measured in this run -- PMC counters need rocprofv3 passes of their
+    # own (tools/hbm_pmc.sh: FETCH_SIZE and WRITE_SIZE separately, FETCH_SIZE doubled for gfx950);
+    # the figure is read from the committed summary of such a run on the same workload and labelled
+    traffic = traffic_source = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
-    if not os.path.exists(pmc_path):
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
             if pmc.get("workload") == args.workload and pmc.get("frames") == T and \
                     pmc.get("streams") == S:
                 traffic = pmc.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/pmc_%s.json (%s; separate rocprofv3 --pmc passes, not this run)" % (
+                    args.workload, pmc.get("round", "round 1"))
         except Exception:
-            traffic = None
+            traffic = traffic_source = None
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
         "kernel": "k_eq_pipe" if eq else "k_run_fast", "kernel_avg_ms": round(kern_avg_ms, 4),
         "launches": launches, "algorithmic_bytes_per_sample": bps,
         "algorithmic_bytes_per_launch": samples_per_step_rank * bps,
     }
 
+    collective = "none"
+    if node_vu:
+        collective = ("RCCL: per %d blocks one ncclAllReduce(int64, sum) + one ncclAllReduce(uint64, max) over "
+                      "their node records (17 + 17 words each), through cmhip_node_allreduce" % NB)
+        if rehearsal and world > 1:
+            collective += " [rehearsal: one-rank communicators + host merge over gloo]"
+        elif not node_on:
+            collective += " [one rank: nothing to exchange]"
     out = {
         "metric": "Msamples/s transform->vumeter", "value": round(value, 1), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "warmup_steps_effective": warm_steps, "warmup_ms_effective": round(warm_ms, 1),
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "int16" if not eq else "f32",
         "arithmetic": "int16 PCM, exact int32 products / division, int64 VU accumulation, dB in f64 on the host"
@@ -290,10 +393,42 @@ def main():
         "data": "synthetic (per-stream LCG noise generated on device, seed 12345 + stream id)",
         "config": {"workload": "%s: %s" % (args.workload, desc), "streams_per_gpu": S,
                    "channels": Cn, "frames_per_launch": T, "sharding": "stream s -> rank s %% %d" % world,
-                   "collective": ("RCCL all-gather of %d blocks' node records (34 x int64 each), combined on the "
-                                  "device" % NB) if node_vu else "none"},
+                   "collective": collective},
+        "per_gpu_Msamples_s": round(value / world, 1),
         "roofline": roofline,
     }
+    if rehearsal:
+        out["rehearsal"] = "all %d ranks share GPU 0 (COOLMIC_BENCH_REHEARSAL=1): not a scaling number" % world
+
+    if node_on and node_last[0] is not None:
+        # the last exchanged set, decoded (outside the timed region)
+        k, count = node_last[0]
+        words = node.fetch(k, count)[count - 1]
+        if rehearsal and world > 1:
+            mine = torch.from_numpy(words.copy())
+            parts = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            import numpy as np
+            words = cm.node_merge_host(np.stack([p.numpy() for p in parts]))
+        rc, r = cm.node_finish(words, Cn)
+        if rc == 0:
+            out["node_vu_last_block"] = {"frames": r.frames, "global_peak": r.global_peak,
+                                         "global_power_db": r.global_power}
+    if node is not None:
+        node.close()
+
+    # per-GPU efficiency against the committed N=1 line of the same workload (the driver computes
+    # its own from its own runs; this is a convenience for a reader of the line)
+    if rank == 0 and world > 1:
+        ref = os.path.join(ROOT, "profiles", "n1_%s.json" % args.workload)
+        try:
+            one = json.load(open(ref))
+            if one.get("config", {}).get("streams_per_gpu") == S and \
+                    one.get("config", {}).get("frames_per_launch") == T and not args.strong:
+                out["per_gpu_efficiency"] = round(value / world / one["value"], 4)
+                out["per_gpu_efficiency_source"] = "profiles/n1_%s.json (N=1 line of the same workload)" % args.workload
+        except Exception:
+            pass
 
     if rank == 0 and not args.no_extras and not eq:
         extras = {}
@@ -306,7 +441,7 @@ def main():
         # the small-block regime, same batch, fewer frames per launch (kernel only)
         sweep = {}
         try:
-            for frames in (512, 4096):
+            for frames in (512, 2880, 4096):
                 if frames >= T:
                     continue
                 b.vu_reset(-1)
@@ -326,6 +461,18 @@ def main():
         out["small_blocks_kernel_only"] = sweep
     b.close()
 
+    def kernel_only(batch, frames, warm=100, timed=100):
+        for _ in range(warm):
+            batch.run(frames)
+        batch.sync()
+        batch.timing(True)
+        batch.timing_read()
+        for _ in range(timed):
+            batch.run(frames)
+        ms, n = batch.timing_read()
+        batch.close()
+        return ms / n
+
     if rank == 0 and not args.no_extras and not eq:
         # second line of SURVEY 8(d): VU only, 2 B/sample read -- never mixed with the above
         v = cm.Batch(S, Cn, T, flags=cm.VU, device=local_rank)
@@ -335,19 +482,11 @@ def main():
         else:
             v.set_gain(-1, 1, 1000, [900])
         v.generate(cm.GEN_NOISE, 12345, T, first_global=rank, global_step=world)
-        for _ in range(100):
-            v.run(T)
-        v.sync()
-        v.timing(True)
-        v.timing_read()
-        for _ in range(100):
-            v.run(T)
-        ms, n = v.timing_read()
-        v.close()
-        gbs = samples_per_step_rank * 2 / (ms / n * 1e-3) / 1e9
-        out["vu_only"] = {"kernel_avg_ms": round(ms / n, 4), "achieved_GBs": round(gbs, 1),
+        ms1 = kernel_only(v, T)
+        gbs = samples_per_step_rank * 2 / (ms1 * 1e-3) / 1e9
+        out["vu_only"] = {"kernel_avg_ms": round(ms1, 4), "achieved_GBs": round(gbs, 1),
                           "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
-                          "Msamples_per_s_kernel": round(samples_per_step_rank / (ms / n * 1e-3) / 1e6, 1),
+                          "Msamples_per_s_kernel": round(samples_per_step_rank / (ms1 * 1e-3) / 1e6, 1),
                           "algorithmic_bytes_per_sample": 2}
         # the same read-only run with the transform as the reference creates it (gain disabled,
         # ref: src/transform.c:107-108) and with every gain below the scale: shorter arithmetic
@@ -358,17 +497,9 @@ def main():
             if args.workload == "c2":
                 v.set_chmap(-1, [1, 0])
             v.generate(cm.GEN_NOISE, 12345, T, first_global=rank, global_step=world)
-            for _ in range(100):
-                v.run(T)
-            v.sync()
-            v.timing(True)
-            v.timing_read()
-            for _ in range(100):
-                v.run(T)
-            ms, n = v.timing_read()
-            v.close()
-            gbs = samples_per_step_rank * 2 / (ms / n * 1e-3) / 1e9
-            out[key] = {"kernel_avg_ms": round(ms / n, 4), "achieved_GBs": round(gbs, 1),
+            ms1 = kernel_only(v, T)
+            gbs = samples_per_step_rank * 2 / (ms1 * 1e-3) / 1e9
+            out[key] = {"kernel_avg_ms": round(ms1, 4), "achieved_GBs": round(gbs, 1),
                         "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
 
     if rank == 0 and world == 1 and not args.no_extras and args.workload == "c2":
@@ -378,39 +509,129 @@ def main():
             for name, (s_, c_, t_, fl, bps_, eqz) in {
                     "c3_eq_float_planes": (8192, 1, 65536, cm.EQ | cm.OUT_F32, 6, True),
                     "eq_stereo_int16_vu": (4096, 2, 65536, cm.EQ | cm.OUT_PCM | cm.VU, 4, True),
-                    "six_channels_pcm_vu": (2730, 6, 16384, cm.OUT_PCM | cm.VU, 4, False)}.items():
+                    "six_channels_pcm_vu": (2730, 6, 16384, cm.OUT_PCM | cm.VU, 4, False),
+                    "six_channels_vu_only": (2730, 6, 16384, cm.VU, 2, False)}.items():
                 o = cm.Batch(s_, c_, t_, flags=fl, device=local_rank)
                 o.set_gain(-1, 1, 1000, [900])
                 if eqz:
                     o.set_eq(-1, cm.eq3(48000.0))
                 o.generate(cm.GEN_NOISE, 12345, t_)
-                for _ in range(100):                 # ~0.1 s: the clocks the chip then holds
-                    o.run(t_)
-                o.sync()
-                o.timing(True)
-                o.timing_read()
-                for _ in range(100):
-                    o.run(t_)
-                ms, n = o.timing_read()
-                o.close()
-                gbs = s_ * c_ * t_ * bps_ / (ms / n * 1e-3) / 1e9
-                other[name] = {"streams": s_, "channels": c_, "frames": t_, "kernel_avg_ms": round(ms / n, 4),
+                ms1 = kernel_only(o, t_)             # ~0.1 s of warm-up: the clocks the chip then holds
+                gbs = s_ * c_ * t_ * bps_ / (ms1 * 1e-3) / 1e9
+                other[name] = {"streams": s_, "channels": c_, "frames": t_, "kernel_avg_ms": round(ms1, 4),
                                "algorithmic_bytes_per_sample": bps_, "achieved_GBs": round(gbs, 1),
                                "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
         except Exception as e:
             other["error"] = str(e)
         out["other_kernels"] = other
+        try:
+            out["pcie_inclusive"] = pcie_inclusive(cm, local_rank)
+        except Exception as e:
+            out["pcie_inclusive"] = {"error": str(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.workload, Cn)
 
-    if need_torch:
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     sys.stdout.flush()
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
+
+
+def dry_run(args, rank, world, json_fd, shard):
+    uid = exchange_node_id(rank, world, lambda: os.urandom(128)) if args.workload == "c5" else b""
+    out = {"metric": "Msamples/s transform->vumeter", "value": 0.0, "unit": "Msamples/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+           "config": {"workload": args.workload}}
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+        out["clock_max_over_ranks"] = shard.max_over_ranks(dist, 1.0 + rank, device="cpu")
+        ids = [torch.zeros(128, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor(list(uid.ljust(128, b"\0")), dtype=torch.uint8))
+        out["node_id_same_on_all_ranks"] = all(bool((i == ids[0]).all()) for i in ids)
+        ranks = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(ranks, torch.tensor([rank]))
+        out["ranks_seen"] = [int(r.item()) for r in ranks]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
+
+
+def pcie_inclusive(cm, device):
+    """Throughput with the PCM starting and ending in HOST memory (reported
+    separately, never as `value`): (a) pinned host buffers, whole-batch upload -> fused kernel ->
+    download, two batches in flight so copies and kernels overlap; (b) the slots themselves in
+    pinned device-mapped host memory (CMHIP_HOSTPCM): the kernel reads and writes over PCIe."""
+    import numpy as np
+    S, Cn, T = 4096, 2, 16384                   # 256 MiB in + 256 MiB out per block
+    res = {"workload": "config 2 shape, %d x %d x %d per block" % (S, Cn, T), "unit": "Msamples/s"}
+    bs, hin, hout = [], [], []
+    for _ in range(2):
+        bb = cm.Batch(S, Cn, T, flags=cm.OUT_PCM | cm.VU, device=device)
+        bb.set_gain(-1, 2, 1000, [750, 1250])
+        bb.set_chmap(-1, [1, 0])
+        bs.append(bb)
+        hin.append(cm.PinnedPcm(bb))
+        hout.append(cm.PinnedPcm(bb))
+    rng = np.random.default_rng(1)
+    blk = rng.integers(-32768, 32768, size=hin[0].shape[1], dtype=np.int64).astype(np.int16)
+    for h in hin:
+        h.array[:] = blk
+
+    def step(i):
+        bb = bs[i & 1]
+        bb.sync()
+        bb.upload_all(hin[i & 1].ptr, T)
+        bb.run(T)
+        bb.download_all(hout[i & 1].ptr, T)
+
+    for i in range(4):
+        step(i)
+    for bb in bs:
+        bb.sync()
+    steps = 10
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    for bb in bs:
+        bb.sync()
+    dt = time.perf_counter() - t0
+    n = S * Cn * T * steps
+    res["copy_engines_two_batches_in_flight"] = {"value": round(n / dt / 1e6, 1),
+                                                 "GBs_each_direction": round(n * 2 / dt / 1e9, 1),
+                                                 "ms_per_block": round(dt / steps * 1e3, 3)}
+    for h in hin + hout:
+        h.free()
+    for bb in bs:
+        bb.close()
+    z = cm.Batch(S, Cn, T, flags=cm.OUT_PCM | cm.VU | cm.HOSTPCM, device=device)
+    z.set_gain(-1, 2, 1000, [750, 1250])
+    z.set_chmap(-1, [1, 0])
+    for s in range(0, S, 256):
+        z.upload(s, blk[:T * Cn])
+    for _ in range(2):
+        z.run(T)
+    z.sync()
+    steps = 6
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        z.run(T)
+    z.sync()
+    dt = time.perf_counter() - t0
+    z.close()
+    n = S * Cn * T * steps
+    res["zero_copy_slots_in_host_memory"] = {"value": round(n / dt / 1e6, 1),
+                                             "GBs_each_direction": round(n * 2 / dt / 1e9, 1),
+                                             "ms_per_block": round(dt / steps * 1e3, 3)}
+    return res
 
 
 def cpu_baseline(workload, channels):

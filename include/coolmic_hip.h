@@ -146,8 +146,8 @@ int cmhip_batch_vu_raw(cmhip_batch_t *b, unsigned int stream, int64_t *power, in
  *   [17..32] packed peak key per channel     -> combine with MAX
  *   [33]     packed global peak key          -> MAX
  * Keys order by (|peak|, earliest frame, lowest global stream id); decode with
- * cmhip_node_finish().  The all-reduce itself is two RCCL calls on `dst` made by
- * the caller (torch.distributed with backend "nccl" in bench.py). */
+ * cmhip_node_finish().  A host that brings its own collective reduces `dst` itself; one
+ * that wants the engine to do it uses cmhip_node_t below. */
 #define CMHIP_NODE_WORDS      34
 #define CMHIP_NODE_SUM_WORDS  17
 int cmhip_batch_vu_node_partial(cmhip_batch_t *b, void *dst_device, uint64_t first_global,
@@ -155,6 +155,42 @@ int cmhip_batch_vu_node_partial(cmhip_batch_t *b, void *dst_device, uint64_t fir
 /* host: turn a combined record into a result (frames = total frames over streams) */
 int cmhip_node_finish(const int64_t *words, unsigned int channels, unsigned int rate,
                       coolmic_vumeter_result_t *out);
+
+/* The exchange itself, in C over RCCL (xGMI inside a node) -- no Python, no torch: one
+ * cmhip_node_t per GPU (= per rank; one process per GPU, or one thread per GPU of one
+ * process).  It owns two sets of `max_records` record slots on its device, so that the
+ * records of B blocks travel in ONE pair of collectives (the exchange is latency bound) and
+ * a set can be exchanged while the next blocks fill the other.  Per set the sums of all
+ * slots are contiguous and so are the keys:
+ *     ncclAllReduce(sums, B*17, ncclInt64,  ncclSum)     words 0..16  of every record
+ *     ncclAllReduce(keys, B*17, ncclUint64, ncclMax)     words 17..33 of every record
+ * issued as one RCCL group on the node's own HIP stream.  librccl is loaded when the first
+ * node is created (dlopen of librccl.so.1; a host that never asks for the node-global VU
+ * never maps it). */
+typedef struct cmhip_node cmhip_node_t;
+#define CMHIP_NODE_ID_BYTES 128
+/* rank 0 makes the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by
+ * whatever means the host has (a socket, a file, shared memory of one process) */
+int           cmhip_node_unique_id(void *id128);
+/* collective over all ranks (ncclCommInitRank): every rank calls it with the same id */
+cmhip_node_t *cmhip_node_new(int device, int nranks, int rank, const void *id128,
+                             unsigned int max_records);
+void          cmhip_node_free(cmhip_node_t *n);
+int           cmhip_node_ranks(const cmhip_node_t *n);
+/* the batch's current windows -> slot `slot` of set `set` (asynchronous on the batch's
+ * stream; the batch must live on the node's device).  Waits, on the device, for the last
+ * exchange of that set. */
+int cmhip_node_partial(cmhip_node_t *n, cmhip_batch_t *b, unsigned int set, unsigned int slot,
+                       uint64_t first_global, uint64_t global_step);
+/* all-reduce slots 0..count-1 of `set` over the ranks, in place, after everything the batch
+ * `after` (may be NULL) has queued so far; asynchronous -- the host does not wait */
+int cmhip_node_allreduce(cmhip_node_t *n, unsigned int set, unsigned int count, cmhip_batch_t *after);
+/* wait for the exchange of `set` and copy its combined records to the host:
+ * words[count][CMHIP_NODE_WORDS], ready for cmhip_node_finish() */
+int cmhip_node_fetch(cmhip_node_t *n, unsigned int set, unsigned int count, int64_t *words);
+/* "replicas only" form of the same combine on the host (no collective): SUM / MAX of `nranks`
+ * records into out[CMHIP_NODE_WORDS]; the parity check of the RCCL path */
+int cmhip_node_merge_host(const int64_t *records, unsigned int nranks, int64_t *out);
 
 /* ---- measurement ----------------------------------------------------------- */
 /* when enabled every run is bracketed by hipEvents on the batch's stream */

@@ -108,6 +108,14 @@ SIGNATURES = {
     "cmhip_batch_vu_raw": (C.c_int, [_vp, C.c_uint, _vp, _vp, _P(C.c_uint64)]),
     "cmhip_batch_vu_node_partial": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64]),
     "cmhip_node_finish": (C.c_int, [_vp, C.c_uint, C.c_uint, _P(VuResult)]),
+    "cmhip_node_unique_id": (C.c_int, [_vp]),
+    "cmhip_node_new": (_vp, [C.c_int, C.c_int, C.c_int, _vp, C.c_uint]),
+    "cmhip_node_free": (None, [_vp]),
+    "cmhip_node_ranks": (C.c_int, [_vp]),
+    "cmhip_node_partial": (C.c_int, [_vp, _vp, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64]),
+    "cmhip_node_allreduce": (C.c_int, [_vp, C.c_uint, C.c_uint, _vp]),
+    "cmhip_node_fetch": (C.c_int, [_vp, C.c_uint, C.c_uint, _vp]),
+    "cmhip_node_merge_host": (C.c_int, [_vp, C.c_uint, _vp]),
     "cmhip_batch_timing": (C.c_int, [_vp, C.c_int]),
     "cmhip_batch_timing_read": (C.c_int, [_vp, _P(C.c_double), _P(C.c_uint)]),
     "cmhip_batch_ceiling": (C.c_double, [_vp, C.c_int, C.c_size_t, C.c_int]),
@@ -406,6 +414,58 @@ def node_finish(words, channels, rate=48000):
     r = VuResult()
     rc = lib.cmhip_node_finish(w.ctypes.data, channels, rate, C.byref(r))
     return rc, r
+
+
+NODE_ID_BYTES = 128
+
+
+def node_unique_id():
+    """rank 0: the 128-byte id every rank hands to Node() (ncclGetUniqueId)"""
+    buf = (C.c_ubyte * NODE_ID_BYTES)()
+    _check("node_unique_id", lib.cmhip_node_unique_id(buf))
+    return bytes(buf)
+
+
+def node_merge_host(records):
+    """SUM / MAX of per-rank node records on the host (the no-collective form)"""
+    w = np.ascontiguousarray(records, dtype=np.int64).reshape(-1, NODE_WORDS)
+    out = np.zeros(NODE_WORDS, dtype=np.int64)
+    _check("node_merge_host", lib.cmhip_node_merge_host(w.ctypes.data, w.shape[0], out.ctypes.data))
+    return out
+
+
+class Node:
+    """cmhip_node_t: the node-global VU exchange over RCCL, one per GPU / rank"""
+
+    def __init__(self, device, nranks, rank, unique_id, max_records=8):
+        assert len(unique_id) == NODE_ID_BYTES
+        self._id = (C.c_ubyte * NODE_ID_BYTES).from_buffer_copy(unique_id)
+        self.max_records = max_records
+        self.h = lib.cmhip_node_new(device, nranks, rank, self._id, max_records)
+        if not self.h:
+            raise CoolmicError("cmhip_node_new: " + last_error(), ERROR_GENERIC)
+
+    def close(self):
+        if self.h:
+            lib.cmhip_node_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def partial(self, batch, set_, slot, first_global=0, global_step=1):
+        _check("node_partial", lib.cmhip_node_partial(self.h, batch.h, set_, slot, first_global, global_step))
+
+    def allreduce(self, set_, count, after=None):
+        _check("node_allreduce", lib.cmhip_node_allreduce(self.h, set_, count, after.h if after else None))
+
+    def fetch(self, set_, count):
+        out = np.zeros((count, NODE_WORDS), dtype=np.int64)
+        _check("node_fetch", lib.cmhip_node_fetch(self.h, set_, count, out.ctypes.data))
+        return out
 
 
 # ---------------------------------------------------------------------------

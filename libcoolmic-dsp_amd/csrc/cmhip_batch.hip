@@ -30,7 +30,7 @@ using namespace cmhip;
 
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *fmt, ...)
+int cmhip_fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -38,6 +38,7 @@ static int fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
+#define fail cmhip_fail
 
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \
@@ -133,7 +134,26 @@ struct cmhip_batch {
 
     bool timing;
     std::vector<EventPair> ev_used, ev_free;
+    RunTune tune;                          // launcher knobs, read once at creation
 };
+
+static RunTune read_tune()
+{
+    RunTune t{};
+    if (const char *e = getenv("CMHIP_VU_TILE")) {
+        const int v = atoi(e);
+        if (v == 4 || v == 8 || v == 16)
+            t.vu_tile = (uint32_t)v;
+    }
+    if (getenv("CMHIP_WIDE4_F32"))
+        t.wide4_f32 = 1;
+    if (const char *e = getenv("CMHIP_ROWS_RPT")) {
+        const int v = atoi(e);
+        if (v == 8 || v == 16 || v == 32)      // the tile sizes the kernels are tested with
+            t.rows_rpt = (uint32_t)v;
+    }
+    return t;
+}
 
 static inline int use(cmhip_batch_t *b)
 {
@@ -323,6 +343,7 @@ static int batch_init(cmhip_batch_t *b)
     HIP_TRY(hipMalloc((void **)&b->d_dbg, 64 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(b->d_dbg, 0, 64 * sizeof(unsigned long long), b->stream));
     if (d.flags & CMHIP_EQ) {
+        HIP_TRY(prepare_eq(d.device));
         HIP_TRY(hipMalloc((void **)&b->d_eq, S * sizeof(EqParam)));
         HIP_TRY(hipMalloc((void **)&b->d_eqstate, S * d.channels * sizeof(EqState)));   // per channel
         HIP_TRY(hipMemsetAsync(b->d_eq, 0, S * sizeof(EqParam), b->stream));
@@ -417,6 +438,7 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->eq_dirty = false;
     b->nsec = 0;
     b->timing = false;
+    b->tune = read_tune();
     if (batch_init(b) != COOLMIC_ERROR_NONE) {
         cmhip_batch_free(b);
         return nullptr;
@@ -914,7 +936,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.identity_maps = b->all_identity ? 1u : 0u;
         a.identity_gains = b->all_gain_identity ? 1u : 0u;
         a.parity = b->parity;
-        HIP_TRY(launch_run(a, b->stream, ev.a, ev.b));
+        HIP_TRY(launch_run(a, b->tune, b->stream, ev.a, ev.b));
         b->in_flight = true;
     }
     if (b->timing)
@@ -1135,11 +1157,24 @@ extern "C" int cmhip_batch_vu_node_partial(cmhip_batch_t *b, void *dst_device,
         return fail(COOLMIC_ERROR_INVAL, "vu_node_partial: batch without VU");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
+    long long *dst = (long long *)dst_device;
+    return cmhip_batch_node_partial_split(b, dst, dst + CMHIP_NODE_SUM_WORDS, first_global, global_step);
+}
+
+// internal (node.hip): the same record with its sums and its keys in two places
+int cmhip_batch_node_partial_split(cmhip_batch_t *b, long long *dst_sum, long long *dst_key,
+                                   uint64_t first_global, uint64_t global_step)
+{
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
     b->last_done = nullptr;                  // main-stream work on the windows follows the last run
     HIP_TRY(launch_node_partial(b->d_vu, b->d.streams, b->d.channels, b->parity, first_global, global_step,
-                                (long long *)dst_device, b->stream));
+                                dst_sum, dst_key, b->stream));
     return COOLMIC_ERROR_NONE;
 }
+
+int cmhip_batch_device(const cmhip_batch_t *b) { return b->d.device; }
+unsigned int cmhip_batch_flags(const cmhip_batch_t *b) { return b->d.flags; }
 
 extern "C" int cmhip_node_finish(const int64_t *w, unsigned int channels, unsigned int rate,
                                  coolmic_vumeter_result_t *out)

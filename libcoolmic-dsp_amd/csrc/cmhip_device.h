@@ -1,5 +1,5 @@
 // cmhip_device.h -- device-side helpers shared by the kernel files: exact gain arithmetic on packed
-// int16, the VU window key, wave reductions.  (Included by k_block.hip, k_eq.hip, k_misc.hip.)
+// int16, the VU window key, DPP wave reductions.  (Included by k_block.hip, k_eq.hip, k_misc.hip.)
 #ifndef CMHIP_DEVICE_H
 #define CMHIP_DEVICE_H
 
@@ -13,34 +13,6 @@ using u64 = unsigned long long;
 
 
 __device__ __forceinline__ u32 uniform(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// magnitude of trunc(x*g/scale) after saturation; sgn = 0 or -1
-__device__ __forceinline__ u32 gain_mag(int x, u32 g2, u32 magic, u32 shift, int &sgn)
-{
-    sgn = x >> 31;
-    const u32 ax = (u32)((x ^ sgn) - sgn);          // |x| <= 32768
-    const u32 n2 = __umul24(ax, g2);                // 2*|x|*gain < 2^32
-    const u32 qa = __umulhi(n2, magic) >> shift;    // floor(|x|*gain/scale)
-    const u32 lim = 32767u - (u32)sgn;              // 32767, or 32768 for negatives
-    return qa < lim ? qa : lim;
-}
-
-__device__ __forceinline__ u64 wave_sum(u64 v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v += __shfl_down(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ u64 wave_max(u64 v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const u64 w = __shfl_down(v, o, 64);
-        v = w > v ? w : v;
-    }
-    return v;
-}
 
 __device__ __forceinline__ u64 make_key(u32 mag, u64 index, u32 neg)
 {
@@ -132,12 +104,6 @@ struct PowAcc {
     u64 total;
     u32 part;
     u32 n;
-    __device__ __forceinline__ void add(u32 mag)
-    {
-        part += mag * mag;
-        if (++n == 3)
-            flush();
-    }
     // square of one 16-bit half of a packed pair added in a single v_mad_u32_u16
     __device__ __forceinline__ void add_lo(u32 pair)
     {
@@ -183,14 +149,6 @@ __device__ __forceinline__ void store_f32(float *f32s, u64 plane, u32 v, const u
         __builtin_nontemporal_store(l, reinterpret_cast<f32x4 *>(f32s + (u64)v * 4));
         __builtin_nontemporal_store(r, reinterpret_cast<f32x4 *>(f32s + plane + (u64)v * 4));
     }
-}
-
-// scalar form of the same arithmetic, used for the samples of a ragged tail
-__device__ __forceinline__ int gain1(int x, u32 g2, u32 magic, u32 shift, u32 &mag)
-{
-    int sg;
-    mag = gain_mag(x, g2, magic, shift, sg);
-    return (int)((mag ^ (u32)sg) - (u32)sg);
 }
 
 // value of another lane by DPP (0 where the source lane is outside the row)

@@ -86,6 +86,15 @@ struct RunArgs {
     uint32_t       identity_gains; // 1 when no stream of the batch has a gain (disabled or unity everywhere)
 };
 
+// Tuning knobs of the block kernels' launcher, read from the environment ONCE, when a batch is
+// created, and validated there (0 = the built-in choice): $CMHIP_VU_TILE in {4, 8, 16},
+// $CMHIP_WIDE4_F32 set at all, $CMHIP_ROWS_RPT in {8, 16, 32} (tools/ab_tiles.py, bench_generic.py).
+struct RunTune {
+    uint32_t vu_tile;
+    uint32_t wide4_f32;
+    uint32_t rows_rpt;
+};
+
 struct EqArgs {
     const int16_t *in;
     int16_t       *out;            // int16 result or nullptr
@@ -118,13 +127,26 @@ struct GenArgs {
 // launchers (k_block.hip, k_eq.hip, k_misc.hip)
 // (ev_start / ev_stop: optional events that take the kernel's own start and end -- hipExtLaunchKernelGGL
 // stamps them from the dispatch itself, without the extra packets of hipEventRecord around the launch)
-hipError_t launch_run(const RunArgs &a, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hipEvent_t ev_start = nullptr,
+                      hipEvent_t ev_stop = nullptr);
+// (the first launch of an EQ kernel variant on a device raises its dynamic-LDS limit there:
+// prepare_eq does that for a batch's device when the batch is created, launch_eq checks it)
+hipError_t prepare_eq(int device);
 hipError_t launch_eq(const EqArgs &a, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t launch_generate(const GenArgs &a, int mode, hipStream_t st);
 hipError_t launch_node_partial(const VuState *vu, uint32_t streams, uint32_t channels,
                                uint32_t parity, uint64_t first_global, uint64_t global_step,
-                               long long *dst, hipStream_t st);
+                               long long *dst_sum, long long *dst_key, hipStream_t st);
 hipError_t launch_ceiling(int mode, const void *src, void *dst, size_t bytes,
                           unsigned long long *sink, hipStream_t st);
 
 }  // namespace cmhip
+
+// engine internals shared between cmhip_batch.hip and node.hip (not part of the C ABI)
+struct cmhip_batch;
+#define CMHIP_INTERNAL __attribute__((visibility("hidden")))
+CMHIP_INTERNAL int cmhip_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+CMHIP_INTERNAL int cmhip_batch_node_partial_split(struct cmhip_batch *b, long long *dst_sum, long long *dst_key,
+                                                  uint64_t first_global, uint64_t global_step);
+CMHIP_INTERNAL int cmhip_batch_device(const struct cmhip_batch *b);
+CMHIP_INTERNAL unsigned int cmhip_batch_flags(const struct cmhip_batch *b);

@@ -21,7 +21,7 @@
 namespace cmhip {
 
 // read-only runs take bigger tiles to amortise the epilogue (picked per channel count from
-// interleaved A/B runs, tools/ab_tiles.py); $CMHIP_VU_TILE (4, 8, 16) overrides for tuning
+// interleaved A/B runs, tools/ab_tiles.py); RunTune::vu_tile (4, 8, 16) overrides for tuning
 constexpr u32 TILE_U_VUONLY_MONO = 16;         // (8 until the A/B was repeated at sustained clocks: 6.03 -> 6.51 TB/s)
 constexpr u32 TILE_U_VUONLY_STEREO = 16;
 
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
 // ---------------------------------------------------------------------------
 // Launcher of the block kernels: by channel count and by what the batch asks for.
 
-hipError_t launch_run(const RunArgs &a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
+hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const bool pcm = a.out != nullptr, f32 = a.f32 != nullptr, vu = a.vu != nullptr;
     if (a.streams == 0 || a.frames == 0)
@@ -744,12 +744,8 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st, hipEvent_t ev_start, hip
         u32 tile_u = TILE_U;
         if (!pcm && !f32) {
             tile_u = a.channels == 1 ? TILE_U_VUONLY_MONO : TILE_U_VUONLY_STEREO;
-            const char *e = getenv("CMHIP_VU_TILE");
-            if (e) {
-                const int v = atoi(e);
-                if (v == 4 || v == 8 || v == 16)
-                    tile_u = (u32)v;
-            }
+            if (tune.vu_tile)                    // tuning knob, validated when the batch was made
+                tile_u = tune.vu_tile;
         }
         const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
         b.chunks = (u32)((nvec + 64ull * tile_u - 1) / (64ull * tile_u));
@@ -782,7 +778,7 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st, hipEvent_t ev_start, hip
 #undef CMHIP_FAST_RO
 #undef CMHIP_FAST
     } else if ((a.channels == 4 || a.channels == 8) && a.identity_maps && !(a.channels == 8 && !pcm && !f32) &&
-               !(a.channels == 4 && f32 && !getenv("CMHIP_WIDE4_F32"))) {
+               !(a.channels == 4 && f32 && !tune.wide4_f32)) {
         // (4-channel float planes: k_run_wide writes every other float of a line per store;
         // k_run_rows stages the planes through LDS and runs 25 % faster there.  Read-only runs on
         // 8 channels: k_run_rows 4.65 against 4.04 TB/s at sustained clocks.)
@@ -840,8 +836,8 @@ hipError_t launch_run(const RunArgs &a, hipStream_t st, hipEvent_t ev_start, hip
         // instead of 8, 16 channels writing PCM 4-16 % from 16 instead of 32)
         const bool ro = !pcm && !f32;
         u32 rpt = P == 1 ? ((a.channels == 16 && !ro) ? 16u : 32u) : ro ? 16u : (a.identity_maps ? 8u : 16u);
-        if (const char *e = getenv("CMHIP_ROWS_RPT"))          // tuning knob (tools/bench_generic.py)
-            rpt = (u32)atoi(e) ? (u32)atoi(e) : rpt;
+        if (tune.rows_rpt)                                     // tuning knob (tools/bench_generic.py)
+            rpt = tune.rows_rpt;
         const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
         const u64 rows = (nvec + W - 1) / W;
         b.chunks = (u32)((rows + rpt - 1) / rpt);

@@ -1,6 +1,8 @@
 // k_eq.hip -- the pipelined equaliser kernel (BASELINE config 3) and its launcher.
 #include "cmhip_device.h"
 
+#include <mutex>
+
 namespace cmhip {
 
 // ---------------------------------------------------------------------------
@@ -740,14 +742,6 @@ static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st, hipEvent_t ev_
 {
     constexpr size_t lds_bytes = eq_pipe_lds_bytes<NSEC, G>();
     static_assert(lds_bytes <= 160 * 1024, "tiles of a workgroup must fit the LDS");
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, G, CH>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess)
-            return e;
-        configured = true;
-    }
     const u64 rows = (u64)a.streams * (CH == 1 ? 1u : a.channels);      // one row per stream and channel
     const u32 spg = CH == 1 ? G : G / a.channels;
     const u32 grid = a.whole_streams ? (a.streams + spg - 1) / spg : (u32)((rows + G - 1) / G);
@@ -767,10 +761,62 @@ static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st, hipEvent_t e
     return launch_eq_pipe<NSEC, 32, 0>(a, st, ev_start, ev_stop);
 }
 
+// The kernels ask for more dynamic LDS than the default limit; the limit is raised per function
+// AND per device, so every device a batch lives on gets its own pass (a C host may drive all
+// GPUs of a node from one process).  Guarded by a mutex: two threads may create their first
+// batches at the same time.
+template <int NSEC>
+static hipError_t raise_lds_limit()
+{
+    const int bytes = (int)eq_pipe_lds_bytes<NSEC, 32>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, 32, 1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, 32, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, 32, 0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return e;
+}
+
+hipError_t prepare_eq(int device)
+{
+    constexpr int MAX_DEV = 64;
+    static std::mutex mu;
+    static bool done[MAX_DEV];
+    if (device < 0 || device >= MAX_DEV)
+        return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> g(mu);
+    if (done[device])
+        return hipSuccess;
+    int cur = -1;
+    hipError_t e = hipGetDevice(&cur);
+    if (e == hipSuccess && cur != device)
+        e = hipSetDevice(device);
+    if (e == hipSuccess) e = raise_lds_limit<1>();
+    if (e == hipSuccess) e = raise_lds_limit<2>();
+    if (e == hipSuccess) e = raise_lds_limit<3>();
+    if (e == hipSuccess) e = raise_lds_limit<4>();
+    if (cur >= 0 && cur != device)
+        (void)hipSetDevice(cur);
+    if (e == hipSuccess)
+        done[device] = true;
+    return e;
+}
+
 hipError_t launch_eq(const EqArgs &a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (a.streams == 0 || a.frames == 0 || !(a.f32 || a.out || a.vu))
         return hipSuccess;
+    {
+        int dev = -1;                                     // (the engine has made the batch's device current)
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess)
+            e = prepare_eq(dev);
+        if (e != hipSuccess)
+            return e;
+    }
     if (a.channels == 0 || a.channels > MAX_CH)
         return hipErrorInvalidValue;
     switch (a.nsec) {                                     // (0 sections: the caller uses launch_run)

@@ -90,9 +90,28 @@ hipError_t launch_generate(const GenArgs &g, int mode, hipStream_t st)
 // Node partial: one record for all streams of the batch.
 //   node key = |peak| << 46 | (2^29-1 - min(frame,2^29-1)) << 17 | (65535 - stream%65536) << 1 | neg
 
+// (the 17 sums and the 17 keys of a record go to two destinations: contiguous for the one-record
+// form, [slot][17] arrays of a cmhip_node_t set for the RCCL exchange)
+__device__ __forceinline__ u64 wave_sum(u64 v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ u64 wave_max(u64 v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const u64 w = __shfl_down(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(256) void k_node_partial(const VuState *vu, u32 streams, u32 channels,
                                                       u32 parity, u64 first_global, u64 global_step,
-                                                      long long *dst)
+                                                      long long *dst_sum, long long *dst_key)
 {
     __shared__ u64 lsum[MAX_CH + 1];
     __shared__ u64 lkey[MAX_CH + 1];
@@ -141,26 +160,28 @@ __global__ __launch_bounds__(256) void k_node_partial(const VuState *vu, u32 str
     }
     __syncthreads();
     if (threadIdx.x <= MAX_CH) {
-        u64 *d = reinterpret_cast<u64 *>(dst);
         if (lsum[threadIdx.x])
-            atomicAdd(&d[threadIdx.x], lsum[threadIdx.x]);
+            atomicAdd(reinterpret_cast<u64 *>(dst_sum) + threadIdx.x, lsum[threadIdx.x]);
         if (lkey[threadIdx.x])
-            atomicMax(&d[MAX_CH + 1 + threadIdx.x], lkey[threadIdx.x]);
+            atomicMax(reinterpret_cast<u64 *>(dst_key) + threadIdx.x, lkey[threadIdx.x]);
     }
 }
 
 hipError_t launch_node_partial(const VuState *vu, u32 streams, u32 channels, u32 parity,
-                               uint64_t first_global, uint64_t global_step, long long *dst,
-                               hipStream_t st)
+                               uint64_t first_global, uint64_t global_step, long long *dst_sum,
+                               long long *dst_key, hipStream_t st)
 {
-    hipError_t e = hipMemsetAsync(dst, 0, sizeof(long long) * (2 * MAX_CH + 2), st);
+    hipError_t e = hipMemsetAsync(dst_sum, 0, sizeof(long long) * (MAX_CH + 1), st);
+    if (e != hipSuccess)
+        return e;
+    e = hipMemsetAsync(dst_key, 0, sizeof(long long) * (MAX_CH + 1), st);
     if (e != hipSuccess)
         return e;
     u32 grid = (streams + 255) / 256;
     if (grid > 256)
         grid = 256;
     hipLaunchKernelGGL(k_node_partial, dim3(grid), dim3(256), 0, st, vu, streams, channels,
-                       parity, first_global, global_step, dst);
+                       parity, first_global, global_step, dst_sum, dst_key);
     return hipGetLastError();
 }
 

@@ -71,7 +71,7 @@ static void tee_make_room(coolmic_tee_t *t, size_t want)
             t->capacity = want;
         } else {
             coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_NOMEM,
-                                "Can not allocate new buffer");
+                                "tee: growing the shared buffer failed (out of memory)");
         }
     }
     if (t->buffer == NULL)
@@ -97,7 +97,7 @@ static ssize_t tee_pull(coolmic_tee_t *t, size_t want)
     room = t->capacity - t->fill;
     if (t->buffer == NULL || room == 0) {
         coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_NOMEM,
-                            "Physical read failed, buffer=%p, room=%zu", (void *)t->buffer, room);
+                            "tee: no buffer to read upstream into (buffer=%p, room=%zu)", (void *)t->buffer, room);
         return -1;
     }
     if (room > want)

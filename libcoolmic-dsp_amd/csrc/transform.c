@@ -39,6 +39,8 @@ struct coolmic_transform {
     float eq_coef[5 * COOLMIC_DSP_TRANSFORM_MAX_EQ_SECTIONS];
     int eq_clear;                      /* filter state is to be zeroed before the next block */
     int dirty;                         /* device copy is stale */
+    unsigned long gen;                 /* bumped by every setter: dirty / eq_clear are only cleared
+                                        * once the values they were set with have reached the device */
 
     cmhip_batch_t *dev;                /* created at the first read that needs it */
 };
@@ -85,6 +87,17 @@ int coolmic_transform_attach_iohandle(coolmic_transform_t *self, coolmic_iohandl
     return COOLMIC_ERROR_NONE;
 }
 
+/* the parameters read at generation `gen` are on the device (or no device exists yet) */
+static void transform_settled(coolmic_transform_t *t, unsigned long gen)
+{
+    pthread_mutex_lock(&t->lock);
+    if (t->gen == gen) {               /* no setter ran in between */
+        t->dirty = 0;
+        t->eq_clear = 0;
+    }
+    pthread_mutex_unlock(&t->lock);
+}
+
 /* whole frames through the GPU, in place.  0 on success. */
 static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames)
 {
@@ -92,7 +105,8 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
     uint8_t chmap[COOLMIC_DSP_TRANSFORM_MAX_CHANNELS];
     float eq_coef[5 * COOLMIC_DSP_TRANSFORM_MAX_EQ_SECTIONS];
     unsigned int eq_sections;
-    int identity, dirty, eq_clear;
+    unsigned long gen;
+    int identity, dirty, eq_clear, idle;
 
     pthread_mutex_lock(&t->lock);
     scale = t->scale;
@@ -102,13 +116,21 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
     eq_sections = t->eq_sections;
     memcpy(eq_coef, t->eq_coef, sizeof(eq_coef));
     eq_clear = t->eq_clear;
-    t->eq_clear = 0;
     dirty = t->dirty;
-    t->dirty = 0;
+    gen = t->gen;
     pthread_mutex_unlock(&t->lock);
 
-    if (scale == 0 && identity && eq_sections == 0)
-        return 0;                      /* nothing to do, exactly as the reference */
+    /* nothing to do, exactly as the reference (ref: src/transform.c:107-108) -- but a device
+     * that exists must still hear about it: "equaliser off" also clears the filter state, and
+     * a later set_eq() must not filter on from what the old one left behind */
+    idle = scale == 0 && identity && eq_sections == 0;
+    if (idle && t->dev == NULL) {
+        if (dirty || eq_clear)         /* a batch made later starts from zero state and uploads everything */
+            transform_settled(t, gen);
+        return 0;
+    }
+    if (idle && !dirty && !eq_clear)
+        return 0;
 
     if (t->dev == NULL) {
         cmhip_batch_desc_t d;
@@ -128,7 +150,7 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
         }
         dirty = 1;
     }
-    if (dirty) {
+    if (dirty || eq_clear) {
         int rc = cmhip_batch_set_gain(t->dev, 0, scale ? t->channels : 0, scale, gain);
         if (rc == COOLMIC_ERROR_NONE)
             rc = cmhip_batch_set_chmap(t->dev, 0, identity ? NULL : chmap);
@@ -139,9 +161,12 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
         if (rc != COOLMIC_ERROR_NONE) {
             coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, rc, "parameter upload failed: %s",
                                 cmhip_last_error());
-            return -1;
+            return -1;                 /* dirty / eq_clear stay set: the next read tries again */
         }
+        transform_settled(t, gen);
     }
+    if (idle)
+        return 0;
     while (frames) {
         const size_t n = frames < TRANSFORM_SLICE_FRAMES ? frames : TRANSFORM_SLICE_FRAMES;
         if (cmhip_batch_upload(t->dev, 0, pcm, n) != COOLMIC_ERROR_NONE ||
@@ -248,8 +273,10 @@ int coolmic_transform_set_master_gain(coolmic_transform_t *self, unsigned int ch
     } else {
         rc = COOLMIC_ERROR_INVAL;
     }
-    if (rc == COOLMIC_ERROR_NONE)
+    if (rc == COOLMIC_ERROR_NONE) {
         self->dirty = 1;
+        self->gen++;
+    }
     pthread_mutex_unlock(&self->lock);
     return rc;
 }
@@ -274,6 +301,7 @@ int coolmic_transform_set_channel_map(coolmic_transform_t *self, const uint8_t *
     }
     self->map_identity = identity;
     self->dirty = 1;
+    self->gen++;
     pthread_mutex_unlock(&self->lock);
     return COOLMIC_ERROR_NONE;
 }
@@ -292,6 +320,7 @@ int coolmic_transform_set_eq(coolmic_transform_t *self, unsigned int sections, c
         self->eq_clear = 1;            /* off: the next filter starts from silence */
     self->eq_sections = sections;
     self->dirty = 1;
+    self->gen++;
     pthread_mutex_unlock(&self->lock);
     return COOLMIC_ERROR_NONE;
 }

@@ -1,0 +1,56 @@
+"""bench.py starts its own rank processes for --gpus N > 1 (the driver runs `python bench.py
+--gpus N` as one command).  Covered here on the CPU with COOLMIC_BENCH_DRYRUN=1: the launch
+plumbing is real -- N fresh processes, RANK / WORLD_SIZE / MASTER_* handed down, gloo
+rendezvous, config 5's node-id exchange over its own socket, the barrier and the
+max-over-ranks clock, exactly one JSON line from rank 0 -- only the GPU work is left out."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None, timeout=180):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, timeout=timeout,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+
+@pytest.mark.parametrize("n,workload", [(2, "c2"), (2, "c5"), (4, "c4")])
+def test_self_launch_prints_one_line_from_rank0(n, workload):
+    p = _run(["--gpus", str(n), "--steps", "3", "--warmup", "1", "--workload", workload],
+             {"COOLMIC_BENCH_DRYRUN": "1"})
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["dry_run"] is True
+    assert out["ranks_seen"] == list(range(n))
+    assert out["clock_max_over_ranks"] == float(n)          # rank r reports 1 + r: the slowest counts
+    assert out["node_id_same_on_all_ranks"] is True
+    assert out["config"]["workload"] == workload
+
+
+def test_single_rank_needs_no_launcher_and_no_torch():
+    p = _run(["--gpus", "1", "--steps", "3", "--warmup", "1"], {"COOLMIC_BENCH_DRYRUN": "1"})
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    out = json.loads(p.stdout.decode().strip())
+    assert out["n_gpus"] == 1 and "ranks_seen" not in out
+
+
+def test_a_failing_rank_fails_the_launch():
+    """without a GPU (and no dry run) every rank exits with 'no HIP device': the parent must
+    report failure and print no JSON line -- never hang at a barrier"""
+    import __graft_entry__ as ge
+    if ge.load_package().device_count() > 0:
+        pytest.skip("needs a machine without a GPU")
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1"], timeout=120)
+    assert p.returncode != 0
+    assert p.stdout.decode().strip() == ""
+    assert b"no HIP device" in p.stderr
