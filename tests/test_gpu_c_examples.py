@@ -16,7 +16,7 @@ def _build_and_run(tmp_path, name, *args):
     exe = tmp_path / name
     subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-O2",
                     "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".c"),
-                    "-L", LIBDIR, "-lcoolmic-dsp-hip", "-Wl,-rpath," + LIBDIR, "-o", str(exe)],
+                    "-L", LIBDIR, "-lcoolmic-dsp-hip", "-lpthread", "-Wl,-rpath," + LIBDIR, "-o", str(exe)],
                    check=True)
     out = subprocess.run([str(exe)] + [str(a) for a in args], check=True, capture_output=True, text=True,
                          timeout=120)
@@ -59,3 +59,24 @@ def test_group_server_in_c(gpu, golden, tmp_path):
     for line, s in zip(lines[1:], (0, 7)):
         assert line == "stream %d: frames %d peak %d power %.17g" % (
             s, exp["frames"], exp["global_peak"], exp["global_power"])
+
+
+def test_node_vu_in_c(gpu, oracle, tmp_path):
+    """config 5's step loop from plain C (examples/node_vu.c): streams sharded over every GPU the
+    box has (one thread per GPU), node-global VU per block through cmhip_node_* (RCCL).  The
+    result does not depend on the number of GPUs: checked against the oracle over all streams."""
+    S, T, blocks = 48, 2048, 6
+    lines = _build_and_run(tmp_path, "node_vu", S, T, blocks)
+    assert lines[0].startswith("gpus ") and lines[0].endswith("streams %d frames %d blocks %d" % (S, T, blocks))
+    assert len(lines) == 1 + blocks
+    _, g = oracle.gain(1, 1, 1000, [900])
+    pcm = [oracle.gain_apply(g, oracle.lcg(12345 + s, T * blocks), 1).astype(np.int64) for s in range(S)]
+    for k in range(blocks):
+        blk = np.stack([p[k * T:(k + 1) * T] for p in pcm])          # [stream][frame]
+        power = oracle.lib.oracle_power_db(int((blk ** 2).sum()), S * T)
+        mag = np.abs(blk)
+        top = int(mag.max())
+        frames_of_top = [int(np.argmax(mag[s] == top)) if (mag[s] == top).any() else T for s in range(S)]
+        s_first = min(range(S), key=lambda s: (frames_of_top[s], s))  # earliest frame, then lowest stream
+        peak = int(blk[s_first, frames_of_top[s_first]])
+        assert lines[1 + k] == "block %d: frames %d peak %d power %.17g" % (k, S * T, peak, power)

@@ -228,3 +228,40 @@ def test_transform_equaliser_behind_the_handle(gpu, oracle):
     want_plain = oracle.gain_apply(g, oracle.chmap([1, 0], x[20000 * C:], C), C)
     assert np.array_equal(res[20000 * C:], want_plain)
     h.unref(); tr.unref()
+
+
+def test_equaliser_off_and_on_again_starts_from_silence(gpu, oracle):
+    """set_eq(A), read, set_eq(off), read, set_eq(B), read -- with no gain and no map, so that the
+    middle read takes the reference's early-out (ref: src/transform.c:107-108) and never touches
+    the device: "0 sections switches the filter off and clears its state"
+    (include/coolmic-dsp/transform.h), so filter B must start from zero state, not from what A
+    left behind"""
+    cm = gpu
+    C, n = 1, 6000
+    x = oracle.lcg(4711, 3 * n)
+    coef_a = cm.eq3(48000.0)
+    coef_b = np.concatenate([cm.design_biquad(1, 48000.0, 2500.0, 5.0, 1.5), coef_a[5:10], coef_a[:5]])
+    tr = cm.Transform(48000, C)
+    src = cm.IoHandle.from_bytes(x.tobytes(), chunk=1024)
+    assert tr.attach(src) == 0
+    src.unref()
+    h = tr.get_iohandle()
+
+    def pull(nbytes):
+        got = b""
+        while len(got) < nbytes:
+            k, data = h.read(min(4096, nbytes - len(got)))
+            assert k > 0
+            got += data
+        return np.frombuffer(got, np.int16)
+
+    assert tr.set_eq(coef_a) == 0
+    a = pull(2 * n)
+    assert tr.set_eq(None) == 0
+    mid = pull(2 * n)
+    assert tr.set_eq(coef_b) == 0
+    b = pull(2 * n)
+    assert np.array_equal(a, _eq_expect(oracle, cm, x[:n], C, coef_a, 1, [1], None))
+    assert np.array_equal(mid, x[n:2 * n])                      # untouched
+    assert np.array_equal(b, _eq_expect(oracle, cm, x[2 * n:], C, coef_b, 1, [1], None))   # zero state
+    h.unref(); tr.unref()

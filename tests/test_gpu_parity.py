@@ -498,6 +498,56 @@ def test_node_partial_matches_host_merge(gpu, oracle):
     for c in range(C):
         assert r.channel_power[c] == oracle.lib.oracle_power_db(int(pw[c]), S * T)
         assert abs(int(r.channel_peak[c])) == max(abs(int(p[c])) for p in peaks)
+    # the host-side merge of the C ABI ("replicas only" form) is the same combine
+    assert np.array_equal(cm.node_merge_host(np.stack(words)), merged)
+
+
+def test_node_exchange_through_rccl_one_rank(gpu, oracle):
+    """cmhip_node_*: the RCCL path of config 5 with a one-rank communicator (all a 1-GPU box can
+    hold): records of three blocks in slots of both sets, all-reduced by ncclAllReduce(int64, sum) +
+    ncclAllReduce(uint64, max), fetched, and equal to the records cmhip_batch_vu_node_partial writes
+    in one piece -- which test_node_partial_matches_host_merge pins against the oracle"""
+    import torch
+    cm = gpu
+    C, T, S = 2, 4096, 24
+    node = cm.Node(0, 1, 0, cm.node_unique_id(), max_records=3)
+    assert cm.lib.cmhip_node_ranks(node.h) == 1
+    b = cm.Batch(S, C, T, flags=cm.VU)
+    assert b.set_gain(-1, 2, 1000, [750, 1250]) == 0
+    direct = []
+    for k in range(4):
+        b.generate(cm.GEN_NOISE, 99, T, first_global=3, global_step=5, frame_offset=k * T)
+        b.run(T)
+        dst = torch.zeros(cm.NODE_WORDS, dtype=torch.int64, device="cuda:0")
+        b.node_partial(dst.data_ptr(), first_global=3, global_step=5)
+        set_, slot = (0, k) if k < 3 else (1, 0)
+        node.partial(b, set_, slot, first_global=3, global_step=5)
+        b.sync()
+        direct.append(dst.cpu().numpy())
+        b.vu_reset(-1)
+        if k == 2:
+            node.allreduce(0, 3, after=b)
+    node.allreduce(1, 1, after=b)
+    got0 = node.fetch(0, 3)
+    got1 = node.fetch(1, 1)
+    for k in range(3):
+        assert np.array_equal(got0[k], direct[k]), k
+    assert np.array_equal(got1[0], direct[3])
+    rc, r = cm.node_finish(got0[1], C)
+    assert rc == 0 and r.frames == S * T
+    # a set can be refilled after its exchange (the batch's stream waits for it on the device)
+    b.generate(cm.GEN_NOISE, 99, T, first_global=3, global_step=5)
+    b.run(T)
+    node.partial(b, 0, 0, first_global=3, global_step=5)
+    node.allreduce(0, 1, after=b)
+    assert np.array_equal(node.fetch(0, 1)[0], direct[0])
+    # argument checks
+    assert cm.lib.cmhip_node_partial(node.h, b.h, 2, 0, 0, 1) == cm.ERROR_INVAL
+    assert cm.lib.cmhip_node_partial(node.h, b.h, 0, 3, 0, 1) == cm.ERROR_INVAL
+    assert cm.lib.cmhip_node_allreduce(node.h, 0, 4, None) == cm.ERROR_INVAL
+    assert cm.lib.cmhip_node_new(0, 2, 2, (cm.C.c_ubyte * 128)(), 4) is None
+    b.close()
+    node.close()
     assert r.global_power == oracle.lib.oracle_power_db(int(pw.sum()), S * T * C)
     assert abs(int(r.global_peak)) == max(abs(int(v)) for p in peaks for v in p)
 
