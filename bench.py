@@ -227,22 +227,6 @@ def main():
     node_on = node_vu and (world > 1 or force_node)
     NB = max(1, args.node_batch)
 
-    node = None
-    if node_on:
-        if rehearsal:
-            node = cm.Node(local_rank, 1, 0, cm.node_unique_id(), max_records=NB)
-        else:
-            uid = exchange_node_id(rank, world, cm.node_unique_id)
-            node = cm.Node(local_rank, world, rank, uid, max_records=NB)
-
-    torch = dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29599")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-
     if eq:
         flags = cm.EQ | cm.OUT_F32
     else:
@@ -260,6 +244,24 @@ def main():
     assert n_local == S
     b.generate(cm.GEN_NOISE, 12345, T, first_global=first_global, global_step=global_step)
     b.sync()
+
+    # (the batch's PCM arrays are allocated before RCCL takes its buffers: the same order of
+    # allocations as in the workloads without an exchange)
+    node = None
+    if node_on:
+        if rehearsal:
+            node = cm.Node(local_rank, 1, 0, cm.node_unique_id(), max_records=NB)
+        else:
+            uid = exchange_node_id(rank, world, cm.node_unique_id)
+            node = cm.Node(local_rank, world, rank, uid, max_records=NB)
+
+    torch = dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29599")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     has_vu = bool(flags & cm.VU)
     results = (cm.VuResult * S)()

@@ -147,9 +147,11 @@ static RunTune read_tune()
     }
     if (getenv("CMHIP_WIDE4_F32"))
         t.wide4_f32 = 1;
+    if (getenv("CMHIP_EQ_GENERAL_GAIN"))        // A/B knob: the EQ kernel's T-in waves take the general gain form
+        t.eq_general = 1;
     if (const char *e = getenv("CMHIP_ROWS_RPT")) {
         const int v = atoi(e);
-        if (v == 8 || v == 16 || v == 32)      // the tile sizes the kernels are tested with
+        if (v == 8 || v == 16 || v == 32 || v == 64)      // the tile sizes the kernels are tested with
             t.rows_rpt = (uint32_t)v;
     }
     return t;
@@ -196,8 +198,8 @@ static void rebuild_param(cmhip_batch_t *b, unsigned int s)
         for (unsigned c = 0; c < MAX_CH; c++) {
             const uint32_t g = b->h_gain[(size_t)s * MAX_CH + c];
             p.gain2[c] = 2u * g;
-            if (c < 2)                       // ceil(g * 2^32 / scale); below 2^32 exactly when g < scale
-                q.kmul[c] = g < scale ? (uint32_t)((((uint64_t)g << 32) + scale - 1) / scale) : 0u;
+            // ceil(g * 2^32 / scale); below 2^32 exactly when g < scale
+            q.kmul[c] = g < scale ? (uint32_t)((((uint64_t)g << 32) + scale - 1) / scale) : 0u;
             if (c < b->d.channels && g >= scale)
                 below = false;
         }
@@ -902,6 +904,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.out = (b->d.flags & CMHIP_OUT_PCM) ? b->d_out : nullptr;
         a.f32 = b->d_f32;
         a.param = b->d_param;
+        a.gshort = b->tune.eq_general ? nullptr : b->d_gshort;
         a.eq = b->d_eq;
         a.state = b->d_eqstate;
         a.vu = vu ? b->d_vu : nullptr;
@@ -1158,18 +1161,23 @@ extern "C" int cmhip_batch_vu_node_partial(cmhip_batch_t *b, void *dst_device,
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     long long *dst = (long long *)dst_device;
-    return cmhip_batch_node_partial_split(b, dst, dst + CMHIP_NODE_SUM_WORDS, first_global, global_step);
+    return cmhip_batch_node_partial_split(b, dst, dst + CMHIP_NODE_SUM_WORDS, first_global, global_step, 1);
 }
 
 // internal (node.hip): the same record with its sums and its keys in two places
 int cmhip_batch_node_partial_split(cmhip_batch_t *b, long long *dst_sum, long long *dst_key,
-                                   uint64_t first_global, uint64_t global_step)
+                                   uint64_t first_global, uint64_t global_step, int clear)
 {
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
-    b->last_done = nullptr;                  // main-stream work on the windows follows the last run
+    // This kernel reads the windows after the last run, on the same stream: its own end, stamped by
+    // its dispatch, is what the next snapshot has to wait for -- no event packet on the main stream.
+    hipEvent_t done = b->ev_done[b->done_next];
+    b->done_next = (b->done_next + 1u) & 3u;
+    b->last_done = nullptr;
     HIP_TRY(launch_node_partial(b->d_vu, b->d.streams, b->d.channels, b->parity, first_global, global_step,
-                                dst_sum, dst_key, b->stream));
+                                dst_sum, dst_key, clear != 0, b->stream, done));
+    b->last_done = done;
     return COOLMIC_ERROR_NONE;
 }
 

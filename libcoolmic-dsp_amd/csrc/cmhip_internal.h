@@ -26,8 +26,8 @@ struct StreamParam {
     uint8_t  chmap[MAX_CH];    // out channel c reads in channel chmap[c]
 };
 
-// Shorter forms of the same arithmetic for the runs that the VALU binds (mono / stereo with a VU window
-// and no PCM result).  mode 2: the gain is disabled or every gain equals the scale -- the magnitudes
+// Shorter forms of the same arithmetic for the runs that the VALU binds (a VU window and no PCM
+// result; mono / stereo: k_run_fast, any other channel count: k_run_rows).  mode 2: the gain is disabled or every gain equals the scale -- the magnitudes
 // are the samples' own.  mode 1: every gain of the stream is below its scale -- with
 // kmul[c] = ceil(gain[c] * 2^32 / scale) the quotient floor(|x|*gain/scale) is mulhi(|x|, kmul[c]) for
 // every |x| <= 32768 (the error term |x| * (kmul*scale - gain*2^32) stays below 2^31), and it never
@@ -35,8 +35,7 @@ struct StreamParam {
 // (A table of its own: growing StreamParam from 96 to 168 bytes cost the config-2 kernel 2-4 %.)
 struct GainShort {
     uint32_t mode;
-    uint32_t kmul[2];
-    uint32_t pad;
+    uint32_t kmul[MAX_CH];
 };
 constexpr uint32_t GAIN_GENERAL = 0, GAIN_BELOW_SCALE = 1, GAIN_IDENTITY = 2;
 
@@ -88,11 +87,12 @@ struct RunArgs {
 
 // Tuning knobs of the block kernels' launcher, read from the environment ONCE, when a batch is
 // created, and validated there (0 = the built-in choice): $CMHIP_VU_TILE in {4, 8, 16},
-// $CMHIP_WIDE4_F32 set at all, $CMHIP_ROWS_RPT in {8, 16, 32} (tools/ab_tiles.py, bench_generic.py).
+// $CMHIP_WIDE4_F32 set at all, $CMHIP_ROWS_RPT in {8, 16, 32, 64} (tools/ab_tiles.py, bench_generic.py).
 struct RunTune {
     uint32_t vu_tile;
     uint32_t wide4_f32;
     uint32_t rows_rpt;
+    uint32_t eq_general;
 };
 
 struct EqArgs {
@@ -100,6 +100,7 @@ struct EqArgs {
     int16_t       *out;            // int16 result or nullptr
     float         *f32;            // float result or nullptr
     const StreamParam *param;
+    const GainShort *gshort;       // per stream: the shorter gain forms (nullptr: general form only)
     const EqParam *eq;
     EqState       *state;
     VuState       *vu;             // VU of the int16 result, or nullptr
@@ -136,7 +137,8 @@ hipError_t launch_eq(const EqArgs &a, hipStream_t st, hipEvent_t ev_start = null
 hipError_t launch_generate(const GenArgs &a, int mode, hipStream_t st);
 hipError_t launch_node_partial(const VuState *vu, uint32_t streams, uint32_t channels,
                                uint32_t parity, uint64_t first_global, uint64_t global_step,
-                               long long *dst_sum, long long *dst_key, hipStream_t st);
+                               long long *dst_sum, long long *dst_key, bool clear, hipStream_t st,
+                               hipEvent_t ev_stop = nullptr);
 hipError_t launch_ceiling(int mode, const void *src, void *dst, size_t bytes,
                           unsigned long long *sink, hipStream_t st);
 
@@ -147,6 +149,6 @@ struct cmhip_batch;
 #define CMHIP_INTERNAL __attribute__((visibility("hidden")))
 CMHIP_INTERNAL int cmhip_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 CMHIP_INTERNAL int cmhip_batch_node_partial_split(struct cmhip_batch *b, long long *dst_sum, long long *dst_key,
-                                                  uint64_t first_global, uint64_t global_step);
+                                                  uint64_t first_global, uint64_t global_step, int clear);
 CMHIP_INTERNAL int cmhip_batch_device(const struct cmhip_batch *b);
 CMHIP_INTERNAL unsigned int cmhip_batch_flags(const struct cmhip_batch *b);

@@ -11,6 +11,7 @@
 #include <coolmic-dsp/iohandle.h>
 #include <coolmic-dsp/logging.h>
 #include <coolmic-dsp/ro-compat.h>
+#include <coolmic-dsp/vumeter.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -23,9 +24,14 @@ int coolmic_sine_period(uint_least32_t rate, int16_t *table, size_t *samples);
 /* HIP device the per-object (non-batch) stages run on: $COOLMIC_HIP_DEVICE or 0 */
 int coolmic_hip_default_device(void);
 
-/* access for stages that want to look through a transform's handle (fusion) */
+/* A VU meter attached directly to a transform's handle shares the transform's launch (vumeter.c,
+ * transform.c): the handle is recognised, the transform accumulates the window, the meter reads it. */
 struct coolmic_transform;
 struct coolmic_transform *coolmic_iohandle_as_transform(coolmic_iohandle_t *h);
+int coolmic_transform_fuse_vu(struct coolmic_transform *self, int on);
+int coolmic_transform_vu_result(struct coolmic_transform *self, coolmic_vumeter_result_t *result);
+int coolmic_transform_vu_reset(struct coolmic_transform *self);
+void coolmic_transform_format(const struct coolmic_transform *self, uint_least32_t *rate, unsigned int *channels);
 
 #ifdef __cplusplus
 }

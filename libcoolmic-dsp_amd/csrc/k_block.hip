@@ -512,10 +512,70 @@ __global__ __launch_bounds__(64) void k_run_wide(RunArgs a)
 
 // STAGE: planar floats go through LDS so that every plane leaves in whole runs (any count but 16,
 // where lanes of equal parity already hold consecutive frames of the same eight channels).
-template <bool WRITE_PCM, bool WRITE_F32, bool DO_VU, bool MAP, bool STAGE, bool IDENT = false>
+//
+// The VU window costs ~3.5 VALU instructions per sample here (it was ~7.5): a lane's eight positions
+// have eight different channels, so nothing can be folded across positions, but the work is done per
+// STEP of UR = 4 rows instead of per row:
+//   * sum of squares: three squares fit a u32 (3 * 2^30), so rows 0-2 of a step are one chain of three
+//     v_mad_u32_u16 and row 3 a fourth; two 64-bit additions per position and step, nothing to decide
+//     at run time (a counter "flush after three" that lives across the row loop costs a compare, two
+//     selects and a 64-bit add per SAMPLE);
+//   * peak: one packed maximum over the step's four rows, one 32-bit key (magnitude << 16 | step) per
+//     position; a lane whose key improves keeps the step's four signed results of that position
+//     (v_bfi_b32 under a mask), and which of the four came first, and its sign, is looked up once
+//     per tile in the epilogue.
+struct RowsVu {
+    u64 pw[8];                                   // sum of squares per position
+    u32 best[8];                                 // |peak| << 16 | (0x7fff - step in tile)
+    u32 sv[4][4];                                // [dword i][row of the step]: the results of the winning step
+};
+
+__device__ __forceinline__ u32 sq_lo0(u32 pair)
+{
+    u32 r;
+    asm("v_mad_u32_u16 %0, %1, %1, 0 op_sel:[0,0,0,0]" : "=v"(r) : "v"(pair));
+    return r;
+}
+__device__ __forceinline__ u32 sq_hi0(u32 pair)
+{
+    u32 r;
+    asm("v_mad_u32_u16 %0, %1, %1, 0 op_sel:[1,1,0,0]" : "=v"(r) : "v"(pair));
+    return r;
+}
+__device__ __forceinline__ u32 sq_lo(u32 pair, u32 acc)
+{
+    asm("v_mad_u32_u16 %0, %1, %1, %0 op_sel:[0,0,0,0]" : "+v"(acc) : "v"(pair));
+    return acc;
+}
+__device__ __forceinline__ u32 sq_hi(u32 pair, u32 acc)
+{
+    asm("v_mad_u32_u16 %0, %1, %1, %0 op_sel:[1,1,0,0]" : "+v"(acc) : "v"(pair));
+    return acc;
+}
+
+// one dword column (positions 2i, 2i+1) of one step: q = packed magnitudes, o = packed signed results
+__device__ __forceinline__ void rows_vu_column(RowsVu &v, const u32 i, const u32 (&q)[4], const u32 (&o)[4],
+                                               const u32 steptag)
+{
+    const u32 m = pk_max(pk_max(q[0], q[1]), pk_max(q[2], q[3]));
+    const u32 klo = (m << 16) | steptag, khi = (m & 0xffff0000u) | steptag;
+    const bool blo = klo > v.best[2 * i], bhi = khi > v.best[2 * i + 1];   // (a later step never wins a tie)
+    v.best[2 * i] = blo ? klo : v.best[2 * i];
+    v.best[2 * i + 1] = bhi ? khi : v.best[2 * i + 1];
+    const u32 mask = (blo ? 0xffffu : 0u) | (bhi ? 0xffff0000u : 0u);
+#pragma unroll
+    for (u32 u = 0; u < 4; u++)
+        v.sv[i][u] = (o[u] & mask) | (v.sv[i][u] & ~mask);
+    v.pw[2 * i] += sq_lo(q[2], sq_lo(q[1], sq_lo0(q[0])));
+    v.pw[2 * i] += sq_lo0(q[3]);
+    v.pw[2 * i + 1] += sq_hi(q[2], sq_hi(q[1], sq_hi0(q[0])));
+    v.pw[2 * i + 1] += sq_hi0(q[3]);
+}
+
+template <bool WRITE_PCM, bool WRITE_F32, bool DO_VU, bool MAP, bool STAGE>
 __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_tile)
 {
-    constexpr u32 UR = 4;                        // rows in flight
+    constexpr u32 UR = 4;                        // rows per step
     __shared__ u64 lsum[MAX_CH];
     __shared__ u64 lkey[MAX_CH];
     __shared__ u32x4 raw[MAP ? UR * 64 : 1];     // the rows as loaded (MAP only)
@@ -556,7 +616,12 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
     const u32 lane_fr = 8u * lane / C;           // whole frames before this lane's vector in a row
     const u32 phase = 8u * lane - lane_fr * C;   // channel of its position 0
     const u32 FW = 8u * W / C;                   // frames per row (8W is a multiple of C)
-    u32 ch[8], df[8], g2[8];
+    // The shorter forms of the gain (GainShort, chosen per stream by the host) where the VALU counts
+    // most: a VU window and nothing written.  The branch is uniform: a wave works on one stream.
+    constexpr bool MODES = DO_VU && !WRITE_PCM && !WRITE_F32;
+    const GainShort *gs = a.gshort + (MODES ? s : 0u);
+    const u32 mode = MODES ? uniform(gs->mode) : GAIN_GENERAL;
+    u32 ch[8], df[8], g2[8], km[8];
     u32 so[8];                                   // MAP: byte offset of position j's source in its row
 #pragma unroll
     for (u32 j = 0; j < 8; j++) {
@@ -564,6 +629,7 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
         df[j] = t / C;
         ch[j] = t - df[j] * C;
         g2[j] = p->gain2[ch[j]];
+        km[j] = MODES ? gs->kmul[ch[j]] : 0u;
         so[j] = MAP ? 2u * ((lane_fr + df[j]) * C + p->chmap[ch[j]]) : 0u;
     }
 
@@ -573,15 +639,94 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
     u32x4 *dst = reinterpret_cast<u32x4 *>(outs);
     float *f32s = WRITE_F32 ? a.f32 + (u64)s * a.plane * C : nullptr;
 
-    PowAcc pw[8];
-    u32 best[8];                                 // |peak| << 16 | (0x7fff - row in tile) << 1 | negative
+    RowsVu vu;
 #pragma unroll
     for (u32 j = 0; j < 8; j++) {
-        pw[j] = PowAcc{0, 0, 0};
-        best[j] = 0;
+        vu.pw[j] = 0;
+        vu.best[j] = 0;
     }
+#pragma unroll
+    for (u32 i = 0; i < 4; i++)
+#pragma unroll
+        for (u32 u = 0; u < UR; u++)
+            vu.sv[i][u] = 0;
 
-    for (u32 r0 = 0; r0 < rows_per_tile; r0 += UR) {
+    auto tile = [&](auto mode_c) {
+    constexpr u32 MODE = decltype(mode_c)::value;
+    // gain + VU of one step: x[u][i] in, the signed results back in o[u][i]
+    auto arithmetic = [&](const u32 step, const u32 (&x)[UR][4], u32 (&o)[UR][4]) {
+        const u32 steptag = 0x7fffu - step;
+#pragma unroll
+        for (u32 i = 0; i < 4; i++) {
+            u32 q[UR], oc[UR];
+#pragma unroll
+            for (u32 u = 0; u < UR; u++) {
+                if constexpr (MODE == GAIN_IDENTITY)
+                    q[u] = gain2_identity(x[u][i], oc[u]);
+                else if constexpr (MODE == GAIN_BELOW_SCALE)
+                    q[u] = gain2_below(x[u][i], km[2 * i], km[2 * i + 1], oc[u]);
+                else
+                    q[u] = gain2(x[u][i], g2[2 * i], g2[2 * i + 1], magic, shift, oc[u]);
+                o[u][i] = oc[u];
+            }
+            if constexpr (DO_VU)
+                rows_vu_column(vu, i, q, oc, steptag);
+        }
+    };
+
+    // Steps of whole rows (every vector inside the stream's whole vectors -- everything but a stream's
+    // ragged end) without channel maps or float planes take a software-pipelined loop: the loads of the next
+    // step are in flight while this step is worked on, all of them unconditional (lanes beyond W
+    // repeat lane W-1's vector; what they compute is dropped at the merge) so that the compiler can
+    // count its waits.  Without it these runs are latency bound: a wave that loads, waits and then
+    // computes leaves the memory idle for as long as it computes.
+    // (a stream's last tile takes it for its whole steps and the ragged loop below for the rest)
+    u32 piped_rows = 0;
+    if (!MAP && !WRITE_F32) {
+        const u64 whole = (u64)nfull / W;                        // rows of whole vectors in the stream
+        const u64 here = whole > row0 ? whole - row0 : 0;
+        piped_rows = (u32)(here < rows_per_tile ? here : rows_per_tile) & ~(UR - 1u);
+    }
+    if (piped_rows) {
+        const u32 lw = active ? lane : W - 1u;
+        const u32x4 *srow = src + (u64)row0 * W + lw;
+        u32x4 *drow = dst + (u64)row0 * W + lw;
+        auto load4 = [&](u32 r0, u32 (&xx)[UR][4]) {
+#pragma unroll
+            for (u32 u = 0; u < UR; u++) {
+                const u32x4 w = __builtin_nontemporal_load(srow + (u64)(r0 + u) * W);
+                xx[u][0] = w.x; xx[u][1] = w.y; xx[u][2] = w.z; xx[u][3] = w.w;
+            }
+        };
+        auto work4 = [&](u32 r0, const u32 (&xx)[UR][4]) {
+            u32 o[UR][4];
+            arithmetic(r0 / UR, xx, o);
+            if constexpr (WRITE_PCM) {
+                if (active) {
+#pragma unroll
+                    for (u32 u = 0; u < UR; u++) {
+                        const u32x4 ov = {o[u][0], o[u][1], o[u][2], o[u][3]};
+                        __builtin_nontemporal_store(ov, drow + (u64)(r0 + u) * W);
+                    }
+                }
+            }
+        };
+        // (every pass of the loop issues its loads unconditionally -- the last step is peeled off)
+        u32 xa[UR][4], xb[UR][4];
+        load4(0, xa);
+        u32 r0 = 0;
+        for (; r0 + UR < piped_rows; r0 += UR) {
+            load4(r0 + UR, xb);
+            work4(r0, xa);
+#pragma unroll
+            for (u32 u = 0; u < UR; u++)
+#pragma unroll
+                for (u32 i = 0; i < 4; i++)
+                    xa[u][i] = xb[u][i];
+        }
+        work4(r0, xa);
+    }
+    for (u32 r0 = piped_rows; r0 < rows_per_tile; r0 += UR) {
         if ((u64)(row0 + r0) * W >= nvec)
             break;
         u32 x[UR][4];
@@ -624,26 +769,15 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
                 }
             }
         }
+        u32 o[UR][4];
+        arithmetic(r0 / UR, x, o);
 #pragma unroll
         for (u32 u = 0; u < UR; u++) {
             const u32 row = row0 + r0 + u;
             const u32 v = row * W + lane;
-            u32 o[4];
-            const u32 tag = (0x7fffu - (r0 + u)) << 1;
-#pragma unroll
-            for (u32 i = 0; i < 4; i++) {
-                const u32 qw = IDENT ? gain2_identity(x[u][i], o[i])
-                                     : gain2(x[u][i], g2[2 * i], g2[2 * i + 1], magic, shift, o[i]);
-                if constexpr (DO_VU) {
-                    best[2 * i] = max(best[2 * i], (qw << 16) | tag | ((x[u][i] >> 15) & 1u));
-                    best[2 * i + 1] = max(best[2 * i + 1], (qw & 0xffff0000u) | tag | (x[u][i] >> 31));
-                    pw[2 * i].add_lo(qw);
-                    pw[2 * i + 1].add_hi(qw);
-                }
-            }
             if (full[u]) {
                 if constexpr (WRITE_PCM) {
-                    const u32x4 ov = {o[0], o[1], o[2], o[3]};
+                    const u32x4 ov = {o[u][0], o[u][1], o[u][2], o[u][3]};
                     __builtin_nontemporal_store(ov, dst + v);
                 }
             } else if (tail[u]) {
@@ -653,7 +787,7 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
 #pragma unroll
                         for (u32 i = 0; i < 4; i++)
                             if (i == (j >> 1))
-                                ow = o[i];
+                                ow = o[u][i];
                         outs[(u64)v * 8 + j] = (int16_t)((ow >> (16u * (j & 1u))) & 0xffffu);
                     }
                 }
@@ -667,7 +801,7 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
 #pragma unroll
                     for (u32 j = 0; j < 8; j++) {
                         if (j < cnt) {
-                            const int q = (int)(short)((o[j >> 1] >> (16u * (j & 1u))) & 0xffffu);
+                            const int q = (int)(short)((o[u][j >> 1] >> (16u * (j & 1u))) & 0xffffu);
                             f32s[(u64)ch[j] * a.plane + fr + df[j]] = q * (1.0f / 32768.0f);
                         }
                     }
@@ -675,7 +809,7 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
                     // this lane's eight samples to [channel][frame of the UR-row step]
 #pragma unroll
                     for (u32 j = 0; j < 8; j++) {
-                        const int q = (int)(short)((o[j >> 1] >> (16u * (j & 1u))) & 0xffffu);
+                        const int q = (int)(short)((o[u][j >> 1] >> (16u * (j & 1u))) & 0xffffu);
                         fstage[ch[j] * (UR * FW) + u * FW + lane_fr + df[j]] = q * (1.0f / 32768.0f);
                     }
                 }
@@ -704,19 +838,43 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
             __syncthreads();                              // before the next step overwrites the stage
         }
     }
+    };
+    if constexpr (MODES) {
+        if (mode == GAIN_IDENTITY)
+            tile(std::integral_constant<u32, GAIN_IDENTITY>{});
+        else if (mode == GAIN_BELOW_SCALE)
+            tile(std::integral_constant<u32, GAIN_BELOW_SCALE>{});
+        else
+            tile(std::integral_constant<u32, GAIN_GENERAL>{});
+    } else {
+        tile(std::integral_constant<u32, GAIN_GENERAL>{});
+    }
 
     if constexpr (DO_VU) {
         __syncthreads();                         // accumulators cleared (one wave: cheap)
 #pragma unroll
         for (u32 j = 0; j < 8; j++) {
-            pw[j].flush();
-            if (pw[j].total)
-                atomicAdd(reinterpret_cast<unsigned long long *>(&lsum[ch[j]]), (unsigned long long)pw[j].total);
-            const u32 mag = best[j] >> 16;
+            const u32 i = j >> 1, sh = 16u * (j & 1u);
+            const u32 mag = vu.best[j] >> 16;
+            if (!active)                         // (lanes beyond W held copies in the pipelined loop)
+                continue;
+            if (vu.pw[j])
+                atomicAdd(reinterpret_cast<unsigned long long *>(&lsum[ch[j]]), (unsigned long long)vu.pw[j]);
             if (mag) {
-                const u32 rr = 0x7fffu - ((best[j] >> 1) & 0x7fffu);
-                const u64 v = (u64)(row0 + rr) * W + lane;
-                const u64 key = make_key(mag, base + 8ull * v + j, best[j] & 1u);
+                // the first of the winning step's four results with that magnitude, and its sign
+                const u32 step = 0x7fffu - (vu.best[j] & 0xffffu);
+                u32 first = UR, neg = 0;
+#pragma unroll
+                for (u32 u = 0; u < UR; u++) {
+                    const int sv = (int)(short)((vu.sv[i][u] >> sh) & 0xffffu);
+                    const u32 am = (u32)(sv < 0 ? -sv : sv);
+                    if (am == mag && first == UR) {
+                        first = u;
+                        neg = sv < 0 ? 1u : 0u;
+                    }
+                }
+                const u64 v = (u64)(row0 + step * UR + first) * W + lane;
+                const u64 key = make_key(mag, base + 8ull * v + j, neg);
                 atomicMax(reinterpret_cast<unsigned long long *>(&lkey[ch[j]]), (unsigned long long)key);
             }
         }
@@ -835,7 +993,9 @@ hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hip
         // (at sustained clocks, tools/bench_generic.py: runs with channel maps gain 3-5 % from 16 rows
         // instead of 8, 16 channels writing PCM 4-16 % from 16 instead of 32)
         const bool ro = !pcm && !f32;
-        u32 rpt = P == 1 ? ((a.channels == 16 && !ro) ? 16u : 32u) : ro ? 16u : (a.identity_maps ? 8u : 16u);
+        // (read-only runs: 64 rows -- the merge at the end of a tile costs as much as two steps of the
+        // loop; 5.2-6.0 TB/s against 4.8-5.6 with 16 or 32 rows, round 2)
+        u32 rpt = ro ? 64u : P == 1 ? (a.channels == 16 ? 16u : 32u) : (a.identity_maps ? 8u : 16u);
         if (tune.rows_rpt)                                     // tuning knob (tools/bench_generic.py)
             rpt = tune.rows_rpt;
         const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
@@ -859,10 +1019,6 @@ hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hip
             hipExtLaunchKernelGGL((k_run_rows<P_, F_, V_, true, false>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b, W, rpt);  \
     } while (0)
         if (pcm && !f32 && vu) CMHIP_ROWS(true, false, true);
-        else if (!pcm && !f32 && vu && a.identity_gains && a.identity_maps)
-            hipExtLaunchKernelGGL((k_run_rows<false, false, true, false, false, true>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b, W, rpt);
-        else if (!pcm && !f32 && vu && a.identity_gains)
-            hipExtLaunchKernelGGL((k_run_rows<false, false, true, true, false, true>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b, W, rpt);
         else if (!pcm && !f32 && vu) CMHIP_ROWS(false, false, true);
         else if (pcm && !f32 && !vu) CMHIP_ROWS(true, false, false);
         else if (pcm && f32 && vu) CMHIP_ROWS(true, true, true);

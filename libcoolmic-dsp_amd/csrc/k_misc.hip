@@ -169,19 +169,21 @@ __global__ __launch_bounds__(256) void k_node_partial(const VuState *vu, u32 str
 
 hipError_t launch_node_partial(const VuState *vu, u32 streams, u32 channels, u32 parity,
                                uint64_t first_global, uint64_t global_step, long long *dst_sum,
-                               long long *dst_key, hipStream_t st)
+                               long long *dst_key, bool clear, hipStream_t st, hipEvent_t ev_stop)
 {
-    hipError_t e = hipMemsetAsync(dst_sum, 0, sizeof(long long) * (MAX_CH + 1), st);
-    if (e != hipSuccess)
-        return e;
-    e = hipMemsetAsync(dst_key, 0, sizeof(long long) * (MAX_CH + 1), st);
-    if (e != hipSuccess)
-        return e;
+    if (clear) {                                 // (a cmhip_node_t clears a whole record set at once instead)
+        hipError_t e = hipMemsetAsync(dst_sum, 0, sizeof(long long) * (MAX_CH + 1), st);
+        if (e != hipSuccess)
+            return e;
+        e = hipMemsetAsync(dst_key, 0, sizeof(long long) * (MAX_CH + 1), st);
+        if (e != hipSuccess)
+            return e;
+    }
     u32 grid = (streams + 255) / 256;
     if (grid > 256)
         grid = 256;
-    hipLaunchKernelGGL(k_node_partial, dim3(grid), dim3(256), 0, st, vu, streams, channels,
-                       parity, first_global, global_step, dst_sum, dst_key);
+    hipExtLaunchKernelGGL(k_node_partial, dim3(grid), dim3(256), 0, st, nullptr, ev_stop, 0, vu, streams, channels,
+                          parity, first_global, global_step, dst_sum, dst_key);
     return hipGetLastError();
 }
 

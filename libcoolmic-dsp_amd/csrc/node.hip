@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <vector>
 
 using namespace cmhip;
 
@@ -112,6 +113,10 @@ struct cmhip_node {
     hipEvent_t ev_filled;                  // "the batch has written its records" (recorded on its stream)
     hipEvent_t ev_done[NODE_SETS];         // the exchange of a set has finished
     bool exchanged[NODE_SETS];             // ev_done[set] has been recorded since the set was last filled
+    // A slot is cleared before a batch adds into it -- not slot by slot (two memsets per block) but
+    // the whole set at once, when the first block after an exchange arrives; `filled` marks the
+    // slots written since.
+    std::vector<bool> filled[NODE_SETS];
 };
 
 static long long *set_sums(const cmhip_node_t *n, unsigned set)
@@ -197,7 +202,15 @@ extern "C" cmhip_node_t *cmhip_node_new(int device, int nranks, int rank, const 
         return nullptr;
     }
     cmhip_node_t *n = new cmhip_node();
-    memset(n, 0, sizeof(*n));
+    n->comm = nullptr;
+    n->stream = nullptr;
+    n->d_words = n->h_words = nullptr;
+    n->ev_filled = nullptr;
+    for (unsigned i = 0; i < NODE_SETS; i++) {
+        n->ev_done[i] = nullptr;
+        n->exchanged[i] = false;
+        n->filled[i].assign(max_records, false);       // (the buffer starts zeroed)
+    }
     n->device = device;
     n->nranks = nranks;
     n->rank = rank;
@@ -226,9 +239,15 @@ extern "C" int cmhip_node_partial(cmhip_node_t *n, cmhip_batch_t *b, unsigned in
         if (hipEventQuery(n->ev_done[set]) != hipSuccess)
             HIP_TRY(hipStreamWaitEvent(bs, n->ev_done[set], 0));
         n->exchanged[set] = false;
+        HIP_TRY(hipMemsetAsync(set_sums(n, set), 0, 2u * (size_t)HALF * n->max_records * sizeof(long long), bs));
+        n->filled[set].assign(n->max_records, false);
+    } else if (n->filled[set][slot]) {     // written twice without an exchange between: start it afresh
+        HIP_TRY(hipMemsetAsync(set_sums(n, set) + (size_t)slot * HALF, 0, HALF * sizeof(long long), bs));
+        HIP_TRY(hipMemsetAsync(set_keys(n, set) + (size_t)slot * HALF, 0, HALF * sizeof(long long), bs));
     }
+    n->filled[set][slot] = true;
     return cmhip_batch_node_partial_split(b, set_sums(n, set) + (size_t)slot * HALF,
-                                          set_keys(n, set) + (size_t)slot * HALF, first_global, global_step);
+                                          set_keys(n, set) + (size_t)slot * HALF, first_global, global_step, 0);
 }
 
 extern "C" int cmhip_node_allreduce(cmhip_node_t *n, unsigned int set, unsigned int count, cmhip_batch_t *after)

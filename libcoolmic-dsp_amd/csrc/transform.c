@@ -15,6 +15,7 @@
 #define COOLMIC_COMPONENT "libcoolmic-dsp/transform"
 #include "host_internal.h"
 #include <coolmic-dsp/transform.h>
+#include <coolmic-dsp/vumeter.h>
 #include <coolmic_hip.h>
 
 #include <pthread.h>
@@ -43,6 +44,9 @@ struct coolmic_transform {
                                         * once the values they were set with have reached the device */
 
     cmhip_batch_t *dev;                /* created at the first read that needs it */
+    int fused_vu;                      /* a VU meter sits directly on this transform's handle: the launch
+                                        * that transforms a block also accumulates its window (one launch
+                                        * per pull instead of two; coolmic_transform_fuse_vu) */
 };
 
 static void transform_destroy(void *self)
@@ -123,7 +127,7 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
     /* nothing to do, exactly as the reference (ref: src/transform.c:107-108) -- but a device
      * that exists must still hear about it: "equaliser off" also clears the filter state, and
      * a later set_eq() must not filter on from what the old one left behind */
-    idle = scale == 0 && identity && eq_sections == 0;
+    idle = scale == 0 && identity && eq_sections == 0 && !t->fused_vu;
     if (idle && t->dev == NULL) {
         if (dirty || eq_clear)         /* a batch made later starts from zero state and uploads everything */
             transform_settled(t, gen);
@@ -140,7 +144,9 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
         d.channels = t->channels;
         d.rate = (unsigned int)t->rate;
         d.max_frames = TRANSFORM_SLICE_FRAMES;
-        d.flags = CMHIP_OUT_PCM | CMHIP_INPLACE | CMHIP_EQ | CMHIP_HOSTPCM;
+        /* (always with a VU window: whether a meter reads it is decided later, and a batch made
+         * anew would lose the equaliser's state) */
+        d.flags = CMHIP_OUT_PCM | CMHIP_INPLACE | CMHIP_EQ | CMHIP_HOSTPCM | CMHIP_VU;
         t->dev = cmhip_batch_new(&d);
         if (t->dev == NULL) {
             coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_NOSYS,
@@ -229,6 +235,49 @@ static int transform_handle_eof(void *userdata)
 static int transform_handle_free(void *userdata)
 {
     return coolmic_ro_unref(userdata);
+}
+
+/* ---- the fused VU window (internal: vumeter.c; declared in host_internal.h) ------------------ */
+
+/* A meter attached directly to this transform's handle, with the same rate and channel count,
+ * sees exactly the frames this transform returns (ref: src/simple.c:212-229 wires them through a
+ * tee, config 1 of BASELINE.json directly).  Then one launch does both loops of the reference --
+ * __process (ref: src/transform.c:101-124) and the accumulate loop (ref: src/vumeter.c:161-177).
+ * One meter at a time; the window starts empty. */
+int coolmic_transform_fuse_vu(coolmic_transform_t *self, int on)
+{
+    if (self == NULL)
+        return COOLMIC_ERROR_FAULT;
+    if (on && self->fused_vu)
+        return COOLMIC_ERROR_BUSY;
+    self->fused_vu = on ? 1 : 0;
+    if (self->dev != NULL && cmhip_batch_vu_reset(self->dev, 0) != COOLMIC_ERROR_NONE)
+        return COOLMIC_ERROR_GENERIC;
+    return COOLMIC_ERROR_NONE;
+}
+
+int coolmic_transform_vu_result(coolmic_transform_t *self, coolmic_vumeter_result_t *result)
+{
+    if (self == NULL || result == NULL)
+        return COOLMIC_ERROR_FAULT;
+    if (self->dev == NULL)
+        return COOLMIC_ERROR_INVAL;    /* no frame has passed yet (ref: src/vumeter.c:198-199) */
+    return cmhip_batch_vu_result(self->dev, 0, result);
+}
+
+int coolmic_transform_vu_reset(coolmic_transform_t *self)
+{
+    if (self == NULL)
+        return COOLMIC_ERROR_FAULT;
+    if (self->dev != NULL && cmhip_batch_vu_reset(self->dev, 0) != COOLMIC_ERROR_NONE)
+        return COOLMIC_ERROR_GENERIC;
+    return COOLMIC_ERROR_NONE;
+}
+
+void coolmic_transform_format(const coolmic_transform_t *self, uint_least32_t *rate, unsigned int *channels)
+{
+    *rate = self->rate;
+    *channels = self->channels;
 }
 
 coolmic_iohandle_t *coolmic_transform_get_iohandle(coolmic_transform_t *self)

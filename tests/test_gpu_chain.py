@@ -265,3 +265,63 @@ def test_equaliser_off_and_on_again_starts_from_silence(gpu, oracle):
     assert np.array_equal(mid, x[n:2 * n])                      # untouched
     assert np.array_equal(b, _eq_expect(oracle, cm, x[2 * n:], C, coef_b, 1, [1], None))   # zero state
     h.unref(); tr.unref()
+
+
+def test_meter_directly_on_a_transform_shares_its_launch(gpu, oracle):
+    """A VU meter attached straight to a transform's handle lets the transform's launch accumulate
+    the window (vumeter.c / transform.c, coolmic_transform_fuse_vu).  What the meter reports must
+    not change: windows cut by result() calls between reads of odd sizes, reset(), gain changes
+    between windows, gain off (the reference's early-out: the fused launch still has to run for
+    the window), then the meter moved to a plain source (its own batch again)."""
+    cm = gpu
+    C, frames = 2, 9000
+    x = oracle.lcg(31, frames * C)
+    tr, h, vu = _chain(cm, cm.IoHandle.from_bytes(x.tobytes(), chunk=700), C)
+    pos = 0
+
+    def window(nreads, sizes, gain):
+        nonlocal pos
+        v = oracle.vu_new(C)
+        rcg, g = oracle.gain(C, *gain) if gain else (0, of.Gain())
+        for i in range(nreads):
+            n = vu.read(sizes[i % len(sizes)])
+            assert n >= 0 and n % (2 * C) == 0
+            blk = x[pos // 2: (pos + n) // 2]
+            oracle.vu_accumulate(v, oracle.gain_apply(g, blk, C))
+            pos += n
+        return v
+
+    for gain, sizes, nreads in (((2, 1000, [750, 1250]), [-1, 7, 1000, 3, 4], 9),
+                                (None, [-1, 512], 5),                 # gain off: early-out in the reference
+                                ((1, 3, [2]), [100, -1], 6)):
+        assert tr.set_master_gain(*(gain if gain else (0, 0, None))) == 0
+        v = window(nreads, sizes, gain)
+        rc, r = vu.result()
+        rc_o, r_o = oracle.vu_result(v)
+        assert rc == rc_o == 0 and r.as_dict() == of.vu_result_dict(r_o), gain
+    rc, _ = vu.result()
+    assert rc == cm.ERROR_INVAL                      # nothing since the last result
+    window(2, [-1], (1, 3, [2]))
+    assert vu.reset() == 0                           # drops the frames of those two reads
+    v = window(3, [-1, 64], (1, 3, [2]))
+    rc, r = vu.result()
+    _, r_o = oracle.vu_result(v)
+    assert rc == 0 and r.as_dict() == of.vu_result_dict(r_o)
+    # the meter moves to a plain handle: a batch of its own from here on
+    y = oracle.lcg(32, 3000 * C)
+    src = cm.IoHandle.from_bytes(y.tobytes())
+    assert vu.attach(src) == 0
+    src.unref()
+    while vu.read(-1) > 0:
+        pass
+    v = oracle.vu_new(C)
+    oracle.vu_accumulate(v, y)
+    rc, r = vu.result()
+    _, r_o = oracle.vu_result(v)
+    assert rc == 0 and r.as_dict() == of.vu_result_dict(r_o)
+    # ... and the transform's handle still delivers transformed PCM to whoever reads it
+    _, g = oracle.gain(C, 1, 3, [2])
+    n, data = h.read(400)
+    assert n == 400 and np.array_equal(np.frombuffer(data, np.int16), oracle.gain_apply(g, x[pos // 2: pos // 2 + 200], C))
+    for o in (h, vu, tr):
+        o.unref()

@@ -498,6 +498,8 @@ def test_node_partial_matches_host_merge(gpu, oracle):
     for c in range(C):
         assert r.channel_power[c] == oracle.lib.oracle_power_db(int(pw[c]), S * T)
         assert abs(int(r.channel_peak[c])) == max(abs(int(p[c])) for p in peaks)
+    assert r.global_power == oracle.lib.oracle_power_db(int(pw.sum()), S * T * C)
+    assert abs(int(r.global_peak)) == max(abs(int(v)) for p in peaks for v in p)
     # the host-side merge of the C ABI ("replicas only" form) is the same combine
     assert np.array_equal(cm.node_merge_host(np.stack(words)), merged)
 
@@ -548,8 +550,6 @@ def test_node_exchange_through_rccl_one_rank(gpu, oracle):
     assert cm.lib.cmhip_node_new(0, 2, 2, (cm.C.c_ubyte * 128)(), 4) is None
     b.close()
     node.close()
-    assert r.global_power == oracle.lib.oracle_power_db(int(pw.sum()), S * T * C)
-    assert abs(int(r.global_peak)) == max(abs(int(v)) for p in peaks for v in p)
 
 
 def test_full_size_config2_properties(gpu, oracle):

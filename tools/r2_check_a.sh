@@ -8,6 +8,7 @@ COOLMIC_BENCH_FORCE_NODE=1 python bench.py --workload c5 --no-extras --no-cpu > 
 COOLMIC_BENCH_REHEARSAL=1 python bench.py --gpus 2 --workload c5 --steps 100 --warmup 20 --no-extras --no-cpu > gpurun_out/r2a_reh_c5_2.json 2> gpurun_out/r2a_reh_c5_2.err && \
 COOLMIC_BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 100 --warmup 20 --no-extras --no-cpu > gpurun_out/r2a_reh_c2_2.json 2> gpurun_out/r2a_reh_c2_2.err
 rc=$?
+[ $rc -eq 0 ] && python tools/bench_generic.py > gpurun_out/r2a_generic.txt 2>&1
 tail -5 gpurun_out/r2a_tests.log
 echo "check A rc=$rc"
 exit $rc
