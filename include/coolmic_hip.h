@@ -177,9 +177,10 @@ cmhip_node_t *cmhip_node_new(int device, int nranks, int rank, const void *id128
                              unsigned int max_records);
 void          cmhip_node_free(cmhip_node_t *n);
 int           cmhip_node_ranks(const cmhip_node_t *n);
-/* the batch's current windows -> slot `slot` of set `set` (asynchronous on the batch's
- * stream; the batch must live on the node's device).  Waits, on the device, for the last
- * exchange of that set. */
+/* the batch's current windows -> slot `slot` of set `set` (asynchronous, beside the batch's
+ * next run; the batch must live on the node's device).  Waits, on the device, for the last
+ * exchange of that set, and clears the set when its first slot after an exchange is filled:
+ * fetch a set's results before putting the next block into it. */
 int cmhip_node_partial(cmhip_node_t *n, cmhip_batch_t *b, unsigned int set, unsigned int slot,
                        uint64_t first_global, uint64_t global_step);
 /* all-reduce slots 0..count-1 of `set` over the ranks, in place, after everything the batch

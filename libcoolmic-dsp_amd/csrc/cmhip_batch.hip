@@ -97,6 +97,11 @@ struct cmhip_batch {
     unsigned int cur;
     hipStream_t copy_stream;               // snapshots travel here, beside the next run
     hipEvent_t ev_main, ev_reset[3];
+    // A node partial (cmhip_node_partial) reads the current windows on the copy stream, beside the next
+    // run; node_reading is set until the window set has rotated (snapshot) or the main stream has been
+    // made to wait for the copy stream (settle_node: before anything on the main stream touches them).
+    hipEvent_t ev_node;
+    bool node_reading;
     // The end of the last run as its own dispatch stamped it (hipExtLaunchKernelGGL): what a snapshot
     // makes the copy stream wait for instead of an event recorded behind the kernel -- one packet less
     // on the main stream per step.  nullptr once anything else on the main stream touched the windows.
@@ -147,8 +152,6 @@ static RunTune read_tune()
     }
     if (getenv("CMHIP_WIDE4_F32"))
         t.wide4_f32 = 1;
-    if (getenv("CMHIP_EQ_GENERAL_GAIN"))        // A/B knob: the EQ kernel's T-in waves take the general gain form
-        t.eq_general = 1;
     if (const char *e = getenv("CMHIP_ROWS_RPT")) {
         const int v = atoi(e);
         if (v == 8 || v == 16 || v == 32 || v == 64)      // the tile sizes the kernels are tested with
@@ -251,6 +254,8 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     delete b->pool;
     if (b->ev_main)
         (void)hipEventDestroy(b->ev_main);
+    if (b->ev_node)
+        (void)hipEventDestroy(b->ev_node);
     for (int i = 0; i < 4; i++)
         if (b->ev_done[i])
             (void)hipEventDestroy(b->ev_done[i]);
@@ -337,6 +342,7 @@ static int batch_init(cmhip_batch_t *b)
     b->d_vu = b->d_vu2[0];
     HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&b->ev_node, hipEventDisableTiming));
     for (int i = 0; i < 4; i++)
         HIP_TRY(hipEventCreate(&b->ev_done[i]));
     HIP_TRY(hipMalloc((void **)&b->d_nframes, S * sizeof(uint32_t)));
@@ -412,6 +418,8 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->cur = 0;
     b->copy_stream = nullptr;
     b->ev_main = nullptr;
+    b->ev_node = nullptr;
+    b->node_reading = false;
     b->ev_done[0] = b->ev_done[1] = b->ev_done[2] = b->ev_done[3] = nullptr;
     b->last_done = nullptr;
     b->done_next = 0;
@@ -829,6 +837,17 @@ extern "C" int cmhip_batch_generate(cmhip_batch_t *b, int mode, uint32_t seed, s
 // ---------------------------------------------------------------------------
 // the hot path
 
+// the main stream is about to touch the windows a node partial may still be reading on the copy stream
+static int settle_node(cmhip_batch_t *b)
+{
+    if (b->node_reading) {
+        HIP_TRY(hipEventRecord(b->ev_node, b->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_node, 0));
+        b->node_reading = false;
+    }
+    return COOLMIC_ERROR_NONE;
+}
+
 static int flush_params(cmhip_batch_t *b)
 {
     if (b->param_dirty) {
@@ -885,7 +904,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         HIP_TRY(hipMemcpyAsync(b->d_nframes, frames_per_stream, b->d.streams * sizeof(uint32_t),
                                hipMemcpyHostToDevice, b->stream));
     }
-    if (flush_params(b))
+    if (flush_params(b) || settle_node(b))
         return COOLMIC_ERROR_GENERIC;
 
     const bool vu = (b->d.flags & CMHIP_VU) != 0;
@@ -904,7 +923,6 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.out = (b->d.flags & CMHIP_OUT_PCM) ? b->d_out : nullptr;
         a.f32 = b->d_f32;
         a.param = b->d_param;
-        a.gshort = b->tune.eq_general ? nullptr : b->d_gshort;
         a.eq = b->d_eq;
         a.state = b->d_eqstate;
         a.vu = vu ? b->d_vu : nullptr;
@@ -1010,6 +1028,8 @@ extern "C" int cmhip_batch_vu_result(cmhip_batch_t *b, unsigned int stream,
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     b->last_done = nullptr;                  // main-stream work on the windows follows the last run
+    if (settle_node(b))
+        return COOLMIC_ERROR_GENERIC;
     VuState v;
     HIP_TRY(hipMemcpyAsync(&v, b->d_vu + stream, sizeof(v), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -1050,6 +1070,7 @@ extern "C" int cmhip_batch_vu_snapshot(cmhip_batch_t *b)
     b->reset_pending[i] = true;
     b->cur = (i + 1u) % 3u;
     b->d_vu = b->d_vu2[b->cur];
+    b->node_reading = false;                 // (a node partial of the closed set runs ahead of this copy, same stream)
     if (b->reset_pending[b->cur]) {          // the set we switch to must have been cleared
         // (it was, a launch ago, in the steady state: then the main stream needs no packet for it)
         if (hipEventQuery(b->ev_reset[b->cur]) != hipSuccess)
@@ -1118,6 +1139,8 @@ extern "C" int cmhip_batch_vu_reset(cmhip_batch_t *b, long stream)
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     b->last_done = nullptr;                  // main-stream work on the windows follows the last run
+    if (settle_node(b))
+        return COOLMIC_ERROR_GENERIC;
     if (stream < 0)
         HIP_TRY(hipMemsetAsync(b->d_vu, 0, b->d.streams * sizeof(VuState), b->stream));
     else
@@ -1133,6 +1156,8 @@ extern "C" int cmhip_batch_vu_raw(cmhip_batch_t *b, unsigned int stream, int64_t
     if (stream >= b->d.streams)
         return fail(COOLMIC_ERROR_INVAL, "vu_raw: stream out of range");
     if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    if (settle_node(b))
         return COOLMIC_ERROR_GENERIC;
     VuState v;
     HIP_TRY(hipMemcpyAsync(&v, b->d_vu + stream, sizeof(v), hipMemcpyDeviceToHost, b->stream));
@@ -1172,6 +1197,8 @@ int cmhip_batch_node_partial_split(cmhip_batch_t *b, long long *dst_sum, long lo
         return COOLMIC_ERROR_GENERIC;
     // This kernel reads the windows after the last run, on the same stream: its own end, stamped by
     // its dispatch, is what the next snapshot has to wait for -- no event packet on the main stream.
+    if (settle_node(b))
+        return COOLMIC_ERROR_GENERIC;
     hipEvent_t done = b->ev_done[b->done_next];
     b->done_next = (b->done_next + 1u) & 3u;
     b->last_done = nullptr;
@@ -1180,6 +1207,29 @@ int cmhip_batch_node_partial_split(cmhip_batch_t *b, long long *dst_sum, long lo
     b->last_done = done;
     return COOLMIC_ERROR_NONE;
 }
+
+// internal (node.hip): the record of a cmhip_node_t set, built on the COPY stream -- beside the batch's
+// next run instead of between two runs (the main stream carries nothing for it: 8 us per block of
+// config 5).  The copy stream waits for the last run's own end; a snapshot that follows is behind the
+// kernel on the same stream; anything else that touches the windows goes through settle_node().
+int cmhip_batch_node_partial_side(cmhip_batch_t *b, long long *dst_sum, long long *dst_key,
+                                  uint64_t first_global, uint64_t global_step)
+{
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    if (b->last_done) {
+        HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->last_done, 0));
+    } else {
+        HIP_TRY(hipEventRecord(b->ev_main, b->stream));
+        HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_main, 0));
+    }
+    HIP_TRY(launch_node_partial(b->d_vu, b->d.streams, b->d.channels, b->parity, first_global, global_step,
+                                dst_sum, dst_key, false, b->copy_stream, nullptr));
+    b->node_reading = true;
+    return COOLMIC_ERROR_NONE;
+}
+
+void *cmhip_batch_side_stream(cmhip_batch_t *b) { return (void *)b->copy_stream; }
 
 int cmhip_batch_device(const cmhip_batch_t *b) { return b->d.device; }
 unsigned int cmhip_batch_flags(const cmhip_batch_t *b) { return b->d.flags; }

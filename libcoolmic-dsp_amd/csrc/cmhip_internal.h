@@ -92,7 +92,6 @@ struct RunTune {
     uint32_t vu_tile;
     uint32_t wide4_f32;
     uint32_t rows_rpt;
-    uint32_t eq_general;
 };
 
 struct EqArgs {
@@ -100,7 +99,6 @@ struct EqArgs {
     int16_t       *out;            // int16 result or nullptr
     float         *f32;            // float result or nullptr
     const StreamParam *param;
-    const GainShort *gshort;       // per stream: the shorter gain forms (nullptr: general form only)
     const EqParam *eq;
     EqState       *state;
     VuState       *vu;             // VU of the int16 result, or nullptr
@@ -150,5 +148,8 @@ struct cmhip_batch;
 CMHIP_INTERNAL int cmhip_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 CMHIP_INTERNAL int cmhip_batch_node_partial_split(struct cmhip_batch *b, long long *dst_sum, long long *dst_key,
                                                   uint64_t first_global, uint64_t global_step, int clear);
+CMHIP_INTERNAL int cmhip_batch_node_partial_side(struct cmhip_batch *b, long long *dst_sum, long long *dst_key,
+                                                 uint64_t first_global, uint64_t global_step);
+CMHIP_INTERNAL void *cmhip_batch_side_stream(struct cmhip_batch *b);
 CMHIP_INTERNAL int cmhip_batch_device(const struct cmhip_batch *b);
 CMHIP_INTERNAL unsigned int cmhip_batch_flags(const struct cmhip_batch *b);

@@ -935,11 +935,11 @@ hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hip
 #undef CMHIP_FAST_C
 #undef CMHIP_FAST_RO
 #undef CMHIP_FAST
-    } else if ((a.channels == 4 || a.channels == 8) && a.identity_maps && !(a.channels == 8 && !pcm && !f32) &&
+    } else if ((a.channels == 4 || a.channels == 8) && a.identity_maps && (pcm || f32) &&
                !(a.channels == 4 && f32 && !tune.wide4_f32)) {
         // (4-channel float planes: k_run_wide writes every other float of a line per store;
-        // k_run_rows stages the planes through LDS and runs 25 % faster there.  Read-only runs on
-        // 8 channels: k_run_rows 4.65 against 4.04 TB/s at sustained clocks.)
+        // k_run_rows stages the planes through LDS and runs 25 % faster there.  Read-only runs:
+        // k_run_rows 5.9-6.0 TB/s on 8 channels against 4.0-4.7 for k_run_wide, round 2.)
         RunArgs b = a;
         // tile size: read-only runs take 16 KiB tiles, the rest 8 KiB (tools/bench_generic.py);
         // 16 channels run faster on k_run_rows below (5.6 against 4.7 TB/s)

@@ -9,12 +9,6 @@ namespace cmhip {
 // EQ path: int16 -> channel map -> gain -> x/32768.f -> NSEC biquads (Direct Form I with the
 // fmaf order the oracle fixes) -> float planes and/or int16 (+VU of the int16 result).
 
-// acc = fmaf(a, b, acc), in place (one rounding, as __builtin_fmaf)
-__device__ __forceinline__ void fmac(float &acc, float a, float b)
-{
-    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
-}
-
 // float -> int16 of the EQ result: round to nearest even, saturate, NaN -> 0 (oracle_f32_to_i16)
 __device__ __forceinline__ int f32_to_i16(float y)
 {
@@ -70,50 +64,38 @@ __device__ __forceinline__ int f32_to_i16(float y)
 // any count, the T lanes gather their channel's samples with 16-bit loads.  For CH != 1 the S
 // lanes scatter the int16 result into the interleaved frames.
 //
-// Wave order.  Waves w, w+4, w+8 (and w+12) of a workgroup share a SIMD, and a step lasts as long
-// as the most loaded SIMD needs (issue slots plus the time its waves are blocked on LDS writes).
-//
-// R waves come in PAIRS (round 2).  A recurrence wave that reads its row, runs the 128 FMAs and then
-// stores the 16 result vectors is the pole of the step: ~1,600 clk of the 1,660 a step took, of which
-// the stores -- which block the issuing wave for 25-50 clk each and cannot overlap the wave's own
-// arithmetic -- are more than the FMAs.  Only (y1, y2) carries from one 64-frame block
-// to the next, so two waves A and B share every chain: in even steps A runs the FMAs of a block
-// (results stay in registers) while B stores the block it computed a step earlier, in odd steps the
-// other way round; y1/y2 change hands through eight bytes of LDS per chain at the barrier.  The
-// chain's critical path per block is then the FMAs alone, and a block's Y_k reaches the next stage
-// one step later (HOP 3 instead of 2).
-// (Four T-ff waves of eight rows each, sixteen waves with one of every role per SIMD, measured
-// slower: 0.805 against 0.787 ms, every T-ff wave busy for 1,430 clk of a 1,850 clk step with half
-// the work -- the waves wait for issue slots and for the LDS, not for their own instruction count.)
-//   three / four sections, 14 waves:
-//   {RA0, T-in0, S0, RB0}  {RA1, T-in1, S1, RB1}  {T-ff0, T-in2, S2}  {T-ff1, T-in3, S3}
+// Wave order.  Waves w, w+4 and w+8 of a workgroup share a SIMD, and a step lasts as long as
+// the most loaded SIMD needs (issue slots plus the time its waves are blocked on LDS writes):
+// per step an R wave costs ~1100 clk of that, a T-in wave (load, gain, section 0) ~600, a
+// T-ff wave (feed-forward of the later sections, 16 rows) ~850, an S wave 100-350.  The order
+// below gives every SIMD one long wave, one T-in wave and one S wave:
+//   {T-ff1, T-in0, S0}  {R0, T-in1, S1}  {R1, T-in2, S2}  {T-ff0, T-in3, S3}
+// (measured against eight-wave layouts with the store work on the R / T-ff waves: 0.91 ms
+// against 0.97-1.03 ms on config 3, 0.96 against 1.49 ms with int16 + VU outputs).
 enum : u32 { EQ_R = 0x00, EQ_TIN = 0x10, EQ_TFF = 0x20, EQ_S = 0x30 };
 constexpr u32 EQ_NSW = 4;                        // S waves
-
-constexpr u32 EQ_NTF = 2;                        // T-ff waves (two or more sections): sixteen rows each, in two passes
 
 template <int NSEC, int G>
 constexpr u32 eq_waves()
 {
-    constexpr u32 nrw = (NSEC + 64 / G - 1) / (64 / G);   // R wave pairs
-    return 2 * nrw + G / 8 + (NSEC > 1 ? EQ_NTF : 0) + EQ_NSW;
+    constexpr u32 nrw = (NSEC + 64 / G - 1) / (64 / G);
+    return nrw + G / 8 + (NSEC > 1 ? 2 : 0) + EQ_NSW;
 }
 
-// role of a wave: EQ_R | 2 * pair + (0: FMAs in even steps, 1: in odd steps), EQ_TIN | n, ...
-template <int NRW, bool TFF>
+template <int NRW, int NTF>
 __device__ __forceinline__ u32 eq_role(u32 wave)
 {
-    if constexpr (TFF && NRW == 2) {             // three or four sections
-        constexpr unsigned char t[14] = {EQ_R | 0, EQ_R | 2, EQ_TFF | 0, EQ_TFF | 1, EQ_TIN | 0, EQ_TIN | 1, EQ_TIN | 2,
-                                         EQ_TIN | 3, EQ_S | 0, EQ_S | 1, EQ_S | 2, EQ_S | 3, EQ_R | 1, EQ_R | 3};
+    if constexpr (NTF == 2 && NRW == 2) {        // three or four sections
+        constexpr unsigned char t[12] = {EQ_TFF | 1, EQ_R | 0, EQ_R | 1, EQ_TFF | 0, EQ_TIN | 0, EQ_TIN | 1,
+                                         EQ_TIN | 2, EQ_TIN | 3, EQ_S | 0, EQ_S | 1, EQ_S | 2, EQ_S | 3};
         return t[wave];
-    } else if constexpr (TFF) {                  // two sections: one R pair
-        constexpr unsigned char t[12] = {EQ_R | 0, EQ_TFF | 0, EQ_TFF | 1, EQ_S | 2, EQ_TIN | 0, EQ_TIN | 1,
-                                         EQ_TIN | 2, EQ_TIN | 3, EQ_R | 1, EQ_S | 0, EQ_S | 1, EQ_S | 3};
+    } else if constexpr (NTF == 2) {             // two sections: one R wave
+        constexpr unsigned char t[11] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 2, EQ_TIN | 3, EQ_S | 0, EQ_TIN | 1,
+                                         EQ_TFF | 0, EQ_TFF | 1, EQ_S | 1, EQ_S | 2, EQ_S | 3};
         return t[wave];
     } else {                                     // one section: no T-ff waves
-        constexpr unsigned char t[10] = {EQ_R | 0, EQ_TIN | 1, EQ_TIN | 2, EQ_TIN | 3, EQ_TIN | 0, EQ_S | 0,
-                                         EQ_S | 1, EQ_S | 2, EQ_R | 1, EQ_S | 3};
+        constexpr unsigned char t[9] = {EQ_R | 0, EQ_TIN | 0, EQ_TIN | 1, EQ_TIN | 2, EQ_S | 0, EQ_TIN | 3,
+                                        EQ_S | 1, EQ_S | 2, EQ_S | 3};
         return t[wave];
     }
 }
@@ -128,20 +110,18 @@ void k_eq_pipe(EqArgs a)
     constexpr u32 EP_ROW = EP_TB + 4;             // floats per LDS row
     constexpr u32 EP_TILE = G * EP_ROW;           // floats per buffer slot
     constexpr u32 SPW = 64 / G;                   // sections per R wave
-    constexpr u32 NRW = (NSEC + SPW - 1) / SPW;   // R wave pairs
-    constexpr u32 NTF = NSEC > 1 ? EQ_NTF : 0;    // T-ff waves: PASSES x 8 rows each
-    constexpr u32 PASSES = G / 8 / EQ_NTF;
-    static_assert(PASSES >= 1, "a T-ff wave takes whole passes of eight rows");
+    constexpr u32 NRW = (NSEC + SPW - 1) / SPW;   // R waves
+    constexpr u32 NTF = NSEC > 1 ? 2 : 0;         // T-ff waves: G / 2 rows each, in PASSES of 8 rows
+    constexpr u32 PASSES = 2;
     constexpr u32 NBUF = 2 * NSEC;                // F_0, Y_0, F_1, Y_1, ...
     constexpr u32 SPR = EP_TB / 4;                // store lanes per row (4 frames each)
     constexpr u32 RPI = 64 / SPR;                 // rows per store instruction
     constexpr int DPP_SHR1 = 0x111, DPP_SHL7 = 0x107;
-    constexpr u32 HOP = 3;                        // steps from F_k to F_k+1: FMAs, stores, feed-forward
+    constexpr u32 HOP = 2;                        // steps from F_k to F_k+1
     constexpr u32 NSW = EQ_NSW;
-    extern __shared__ float lds[];                // NBUF buffers x 2 slots x EP_TILE floats, then G counts,
-    u32 *nfr_lds = reinterpret_cast<u32 *>(lds + NBUF * 2 * EP_TILE);      // then y1/y2 of every chain
-    float2 *hst = reinterpret_cast<float2 *>(nfr_lds + G);                 // [section][row]
-    const u32 wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63u;   // (wave number in an SGPR: the role branches are scalar)
+    extern __shared__ float lds[];                // NBUF buffers x 2 slots x EP_TILE floats, then G counts
+    u32 *nfr_lds = reinterpret_cast<u32 *>(lds + NBUF * 2 * EP_TILE);
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const u32 C = MONO ? 1u : STEREO ? 2u : a.channels;
     // Rows are numbered stream * C + channel over the whole batch and a workgroup takes G
     // consecutive ones (rows are independent, so a stream's channels may sit in two workgroups:
@@ -158,7 +138,7 @@ void k_eq_pipe(EqArgs a)
         return r < rows_here ? q : 0xffffffffu;           // (q >= streams: past the end of the batch)
     };
 
-    const u32 role = eq_role<(int)NRW, (NTF != 0)>(wave);
+    const u32 role = eq_role<(int)NRW, (int)NTF>(wave);
     const bool is_rec = (role & 0xf0u) == EQ_R;
     const bool is_tin = (role & 0xf0u) == EQ_TIN;
     const bool is_tff = (role & 0xf0u) == EQ_TFF;
@@ -173,9 +153,8 @@ void k_eq_pipe(EqArgs a)
     const bool is_store = s_cnt != 0;
     const u32 tw = role & 15u;                            // T-in / T-ff wave index
 
-    // R lanes: section and stream row; rpar: the step parity in which this wave of the pair runs FMAs
-    const u32 sec = ((role & 15u) >> 1) * SPW + lane / G;
-    const u32 rpar = role & 1u;
+    // R lanes: section and stream row
+    const u32 sec = (role & 15u) * SPW + lane / G;
     const bool has_sec = is_rec && sec < (u32)NSEC;
     const u32 row = lane % G;
     u32 my_ch;
@@ -191,22 +170,16 @@ void k_eq_pipe(EqArgs a)
         nmax = max(nmax, (u32)__shfl_xor((int)nmax, o, 64));
     const u32 nblocks = (nmax + EP_TB - 1) / EP_TB;
     const u32 nsteps = nblocks + HOP * NSEC;
+    __syncthreads();
 
-    // R lanes: y1, y2 of their section (EqState: x1 x2 y1 y2) live in LDS between the steps
-    float d1 = 0, d2 = 0;
+    // R lanes own y1, y2 of their section (EqState: x1 x2 y1 y2)
+    float d1 = 0, d2 = 0, h1 = 0, h2 = 0;
     if (has_sec && live) {
         const float *c = a.eq[sl].coef[sec];
+        const float *st = a.state[sidx].s[sec];
         d1 = -c[3]; d2 = -c[4];
+        h1 = st[2]; h2 = st[3];
     }
-    if (has_sec && rpar == 0u) {
-        float2 h0 = make_float2(0.f, 0.f);
-        if (live) {
-            const float *st = a.state[sidx].s[sec];
-            h0 = make_float2(st[2], st[3]);
-        }
-        hst[sec * G + row] = h0;
-    }
-    __syncthreads();                                      // frame counts and chain states are in LDS
 
     // T lanes: stream row l_r, frames l_t8 .. l_t8+7 of every block
     const u32 l_r = 8u * tw + lane / 8u;
@@ -217,7 +190,7 @@ void k_eq_pipe(EqArgs a)
     const u32 l_s = min(l_stream, a.streams - 1);
     const bool l_live = is_tin && l_stream < a.streams;
     const u32 l_sidx = l_s * C + l_ch;
-    u32 l_magic = 0, l_shift = 0, l_g2 = 0, l_n = 0, l_m = 0, l_mode = GAIN_GENERAL, l_km = 0;
+    u32 l_magic = 0, l_shift = 0, l_g2 = 0, l_n = 0, l_m = 0;
     // feed-forward registers: b0 b1 b2 and x[t-1], x[t-2] before the next block.  A T-in lane
     // uses [0][0] for section 0 of its row; a T-ff lane [p][k] for section k of the row of pass p.
     float fc[PASSES][NSEC][3];
@@ -234,10 +207,6 @@ void k_eq_pipe(EqArgs a)
         l_shift = a.param[l_s].shift;
         l_g2 = a.param[l_s].gain2[l_ch];
         l_m = MONO ? 0u : a.param[l_s].chmap[l_ch];       // the input channel this row reads
-        if (a.gshort) {
-            l_mode = a.gshort[l_s].mode;
-            l_km = a.gshort[l_s].kmul[l_ch];
-        }
         l_n = nfr_lds[l_r];
         if (l_live) {
             // section 0 sees integer-valued samples (the 2^-15 of "x / 32768.f" is not applied
@@ -263,7 +232,7 @@ void k_eq_pipe(EqArgs a)
         // rows r, r+16, r+17, r+1 in those four groups the sixteen 16-byte columns are all different
         // (rows 68 floats apart: a row shifts the columns by one); with r, r+1, r+2, r+3 two collide.
         {
-            const u32 q = lane / 8u, blk = PASSES * tw + p, sub = q & 3u;
+            const u32 q = lane / 8u, blk = 2u * tw + p, sub = q & 3u;
             f_r[p] = 4u * blk + 2u * (q >> 2) + (sub >> 1) + ((sub == 1u || sub == 2u) ? 16u : 0u);
         }
         if (is_tff) {
@@ -283,9 +252,6 @@ void k_eq_pipe(EqArgs a)
 
     // gain disabled (scale 0, or every gain equal to the scale) is stored as 1/1: x -> x
     const bool gain_off = __all(l_g2 == 2u && l_shift == 0u);
-    // ... and every gain of the wave's rows below its scale (GainShort, cmhip_internal.h): the quotient
-    // is one v_mul_hi_u32 by ceil(gain * 2^32 / scale) and cannot reach the saturation limits
-    const bool gain_below = a.gshort != nullptr && __all(!is_tin || l_mode == GAIN_BELOW_SCALE);
 
     // The T waves keep two blocks of PCM in flight: a block's HBM latency is hidden behind
     // two pipeline steps.  The load is unconditional (address clamped into the stream's own
@@ -344,77 +310,61 @@ void k_eq_pipe(EqArgs a)
     u64 st_busy = 0, st_p[3] = {0, 0, 0};
     const u64 st_begin = __builtin_readcyclecounter();
 #endif
-    // Schedule: F_k of block b is written in step b+3k, the R pair runs its FMAs in step b+3k+1 and
-    // stores Y_k in step b+3k+2, the block leaves in step b+3*NSEC.  Every buffer is read one step
-    // after it was written, so two slots do.
-    // (two functions, called back to back around a barrier by the R loop below: the block then lives
-    // in 64 registers from its LDS reads to its LDS writes within one pass of that loop)
-    const u32 first = HOP * sec + 1u;                     // step in which block 0 is worked on
-    auto rec_fma = [&](const u32 step, float4 (&yv)[EP_TB / 4]) {
-        {
-            // ---- FMAs of block b: F_k row -> registers, y1/y2 from and to LDS.  Every lane runs
-            // them, also one without a block this step (it reads some row and drops the result):
-            // yv is then defined anew by the whole wave and can take the registers of the block
-            // that left a step ago -- under a per-lane condition the compiler has to keep the old
-            // and the new block side by side, 128 registers for them alone.
+    // Schedule: F_k of block b is written in step b+2k, Y_k in step b+2k+1, the block leaves in
+    // step b+2*NSEC.  Every buffer is read one step after it was written, so two slots do.
+    // (Loading an R wave's next row into registers a step ahead was worth 7 % with eight waves
+    // per workgroup; with twelve it needs more registers than three waves per SIMD leave.)
+    auto rec_step = [&](const u32 step) {
+        if (!(CMHIP_EQ_ABL & 32)) {
+            const u32 first = HOP * sec + HOP - 1u;       // step in which block 0 is worked on
             const u32 b = step - first;
-            const bool valid = has_sec && step >= first && b < nblocks;
-            const u32 sa = min(sec, (u32)NSEC - 1u);
-            float2 *hp = hst + sa * G + row;
-            const float2 hh = *hp;
-            const float4 *in = reinterpret_cast<const float4 *>(
-                lds + ((2u * sa) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW);
+            if (has_sec && step >= first && b < nblocks) {
+                float4 *out = reinterpret_cast<float4 *>(
+                    lds + ((2u * sec + 1u) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW);
+                const float4 *in = reinterpret_cast<const float4 *>(
+                    lds + ((2u * sec) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW);
+                float4 v[EP_TB / 4];
 #pragma unroll
-            for (u32 t = 0; t < EP_TB / 4; t++)          // whole row first: 16 LDS reads in flight
-                yv[t] = in[t];
-            float h1 = hh.x, h2 = hh.y;
-            const u32 done = b * EP_TB;
-            const u32 cnt = !valid ? EP_TB : my_nfr > done ? min(my_nfr - done, EP_TB) : 0u;
-            // (v_fmac_f32 through asm: the two FMAs of a sample then work in the register its F value
-            // arrived in, and a block occupies 64 registers from its LDS read to its LDS write)
+                for (u32 t = 0; t < EP_TB / 4; t++)      // whole row first: 16 LDS reads in flight
+                    v[t] = in[t];
+                const u32 done = b * EP_TB;
+                const u32 cnt = my_nfr > done ? min(my_nfr - done, EP_TB) : 0u;
+                if (CMHIP_EQ_ABL & 4) {
 #pragma unroll
-            for (u32 t = 0; t < EP_TB / 4; t++) {
-                float4 &v = yv[t];
-                fmac(v.x, d2, h2); fmac(v.x, d1, h1);
-                fmac(v.y, d2, h1); fmac(v.y, d1, v.x);
-                fmac(v.z, d2, v.x); fmac(v.z, d1, v.y);
-                fmac(v.w, d2, v.y); fmac(v.w, d1, v.z);
-                h2 = v.z;
-                h1 = v.w;
-            }
-            if (!__all(cnt == EP_TB)) {
-                // Some stream ends inside (or before) this block.  Its real samples were computed
-                // as ever; what lies beyond them is never stored; but the history it hands on must
-                // be that of its last real sample: walk the results once more, moving the history
-                // only on real samples (rare, and only reads the block).
-                float n1 = hh.x, n2 = hh.y;
+                    for (u32 t = 0; t < EP_TB / 4; t++)
+                        out[t] = v[t];
+                } else if (__all(cnt == EP_TB)) {
 #pragma unroll
-                for (u32 t = 0; t < EP_TB / 4; t++) {
-                    const float e[4] = {yv[t].x, yv[t].y, yv[t].z, yv[t].w};
+                    for (u32 t = 0; t < EP_TB / 4; t++) {
+                        float4 y;
+                        y.x = __builtin_fmaf(d1, h1, __builtin_fmaf(d2, h2, v[t].x));
+                        y.y = __builtin_fmaf(d1, y.x, __builtin_fmaf(d2, h1, v[t].y));
+                        y.z = __builtin_fmaf(d1, y.y, __builtin_fmaf(d2, y.x, v[t].z));
+                        y.w = __builtin_fmaf(d1, y.z, __builtin_fmaf(d2, y.y, v[t].w));
+                        h2 = y.z;
+                        h1 = y.w;
+                        if (!(CMHIP_EQ_ABL & 8) || t == 0)
+                            out[t] = y;
+                    }
+                } else {
+                    // some stream ends inside this block: same arithmetic, but the history of a
+                    // lane moves only on its real samples (what lies beyond is never stored)
 #pragma unroll
-                    for (u32 j = 0; j < 4; j++) {
-                        const bool real = 4u * t + j < cnt;
-                        n2 = real ? n1 : n2;
-                        n1 = real ? e[j] : n1;
+                    for (u32 t = 0; t < EP_TB / 4; t++) {
+                        const float xs[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+                        float rs[4];
+#pragma unroll
+                        for (u32 j = 0; j < 4; j++) {
+                            const float r = __builtin_fmaf(d1, h1, __builtin_fmaf(d2, h2, xs[j]));
+                            const bool real = 4u * t + j < cnt;
+                            h2 = real ? h1 : h2;
+                            h1 = real ? r : h1;
+                            rs[j] = r;
+                        }
+                        out[t] = make_float4(rs[0], rs[1], rs[2], rs[3]);
                     }
                 }
-                h1 = n1;
-                h2 = n2;
             }
-            if (valid)
-                *hp = make_float2(h1, h2);                // for the other wave of the pair, next step
-        }
-    };
-    auto rec_write = [&](const u32 step, const float4 (&yv)[EP_TB / 4]) {
-        // ---- the block this wave computed a step ago leaves for Y_k (its partner runs the
-        // FMAs of the next block meanwhile)
-        const u32 b = step - first - 1u;
-        if (has_sec && step >= first + 1u && b < nblocks) {
-            float4 *out = reinterpret_cast<float4 *>(
-                lds + ((2u * sec + 1u) * 2u + (b & 1u)) * EP_TILE + row * EP_ROW);
-#pragma unroll
-            for (u32 t = 0; t < EP_TB / 4; t++)
-                out[t] = yv[t];
         }
     };
     float keep1 = 0.f, keep2 = 0.f;                       // section 0's new x1 / x2, if seen
@@ -455,18 +405,6 @@ void k_eq_pipe(EqArgs a)
                     for (u32 q = 0; q < 4; q++) {
                         x[2 * q] = (float)(int)(int16_t)(w[q] & 0xffffu);
                         x[2 * q + 1] = (float)((int)w[q] >> 16);
-                    }
-                } else if (gain_below) {                  // 13 instructions per sample pair instead of ~20
-#pragma unroll
-                    for (u32 q = 0; q < 4; q++) {
-                        const u32 sg = pk_sign(w[q]);
-                        const u32 aw = pk_sub(w[q] ^ sg, sg);
-                        const float m0 = (float)__umulhi(aw & 0xffffu, l_km);
-                        const float m1 = (float)__umulhi(aw >> 16, l_km);
-                        const u32 b0 = (__builtin_bit_cast(u32, m0) & 0x7fffffffu) | ((w[q] << 16) & 0x80000000u);
-                        const u32 b1 = (__builtin_bit_cast(u32, m1) & 0x7fffffffu) | (w[q] & 0x80000000u);
-                        x[2 * q] = __builtin_bit_cast(float, b0);
-                        x[2 * q + 1] = __builtin_bit_cast(float, b1);
                     }
                 } else {
 #pragma unroll
@@ -715,69 +653,12 @@ void k_eq_pipe(EqArgs a)
     // One loop per role (the role never changes, and a loop of its own lets the compiler
     // count a T wave's outstanding loads); every wave passes the same number of barriers.
     const u32 nst2 = (nsteps + 1u) & ~1u;                 // an odd tail step finds nothing to do
-    // (every role's epilogue sits inside its own branch: what one role keeps across its loop is
-    // then not alive in the loops of the others -- fourteen waves leave 128 registers each)
     if (is_rec) {
-        // FMAs in the steps of this wave's parity, stores in the others (nst2 is even; the last
-        // valid FMA step is nsteps - 3, so the odd wave's first and last step have nothing to do)
-        u32 step = 0;
-        if (rpar) {
-            EQ_STEP((void)0);
-            step = 1;
-        }
-        for (; step + 1u < nst2; step += 2) {
-            float4 yv[EP_TB / 4];
-            EQ_STEP(rec_fma(step, yv));
-            EQ_STEP(rec_write(step + 1u, yv));
-        }
-        if (rpar)
-            EQ_STEP((void)0);
-        // state for the next launch (one wave of each pair writes it; the last FMA step left y1/y2 in
-        // LDS, and every step ends with a barrier).  y1/y2 of section k are also the x1/x2 of section
-        // k+1 (its input is this section's output); section 0's x1/x2 were written by the T lanes.
-        if (has_sec && live && rpar == 0u) {
-            const float2 hh = hst[sec * G + row];
-            float *st = a.state[sidx].s[sec];
-            st[2] = hh.x;
-            st[3] = hh.y;
-            if (sec + 1u < (u32)NSEC) {
-                float *sn = a.state[sidx].s[sec + 1u];
-                if (my_nfr >= 2u) {
-                    sn[0] = hh.x;
-                    sn[1] = hh.y;
-                } else if (my_nfr == 1u) {
-                    sn[1] = sn[0];
-                    sn[0] = hh.x;
-                }
-            }
-        }
+        for (u32 step = 0; step < nst2; step++)
+            EQ_STEP(rec_step(step));
     } else if (is_store) {
         for (u32 step = 0; step < nst2; step++)
             EQ_STEP(s_step(step));
-        // VU windows of the int16 result: every wave that did store work holds parts of them
-        if (a.vu) {
-            // the 16 lanes of a row hold parts of its window; lane 0 of them is the row's only writer
-    #pragma unroll
-            for (u32 i = 0; i < NSL; i++) {
-                vky[i] = make_key(vmag[i], vbase[i] + (u64)(vidx[i] >> 1) * C + v_ch[i], vidx[i] & 1u);
-                u64 pw = vpw[i], ky = vky[i];
-    #pragma unroll
-                for (int o = SPR / 2; o > 0; o >>= 1) {
-                    pw += (u64)__shfl_xor((long long)pw, o, 64);
-                    const u64 ok = (u64)__shfl_xor((long long)ky, o, 64);
-                    ky = ok > ky ? ok : ky;
-                }
-                const u32 r = s_row(i);
-                if (lane % SPR == 0 && v_stream[i] != 0xffffffffu) {
-                    VuState *vs = a.vu + v_stream[i];
-                    if (v_ch[i] == 0)
-                        vs->samples[a.parity ^ 1u] = vbase[i] + (u64)nfr_lds[r] * C;
-                    vs->power[v_ch[i]] += pw;
-                    if (ky > vs->key[v_ch[i]])
-                        vs->key[v_ch[i]] = ky;
-                }
-            }
-        }
     } else if (is_tff) {
         for (u32 step = 0; step < nst2; step++)
             EQ_STEP(tff_step(step));
@@ -793,24 +674,67 @@ void k_eq_pipe(EqArgs a)
     }
 #undef EQ_STEP
 
+    // VU windows of the int16 result: every wave that did store work holds parts of them
+    if (is_store && a.vu) {
+        // the 16 lanes of a row hold parts of its window; lane 0 of them is the row's only writer
+#pragma unroll
+        for (u32 i = 0; i < NSL; i++) {
+            vky[i] = make_key(vmag[i], vbase[i] + (u64)(vidx[i] >> 1) * C + v_ch[i], vidx[i] & 1u);
+            u64 pw = vpw[i], ky = vky[i];
+#pragma unroll
+            for (int o = SPR / 2; o > 0; o >>= 1) {
+                pw += (u64)__shfl_xor((long long)pw, o, 64);
+                const u64 ok = (u64)__shfl_xor((long long)ky, o, 64);
+                ky = ok > ky ? ok : ky;
+            }
+            const u32 r = s_row(i);
+            if (lane % SPR == 0 && v_stream[i] != 0xffffffffu) {
+                VuState *vs = a.vu + v_stream[i];
+                if (v_ch[i] == 0)
+                    vs->samples[a.parity ^ 1u] = vbase[i] + (u64)nfr_lds[r] * C;
+                vs->power[v_ch[i]] += pw;
+                if (ky > vs->key[v_ch[i]])
+                    vs->key[v_ch[i]] = ky;
+            }
+        }
+    }
 #ifdef CMHIP_EQ_STAMPS
     if (blockIdx.x == 7 && lane == 0 && a.dbg) {     // per-role busy cycles (tools/eq_stamps.py)
-        a.dbg[2 * wave] = st_busy;                    // words 0..31: busy / total per wave (up to 16)
+        a.dbg[2 * wave] = st_busy;
         a.dbg[2 * wave + 1] = __builtin_readcyclecounter() - st_begin;
-        a.dbg[32 + wave] = role | ((u64)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) << 8);   // role, HW_ID
+        a.dbg[36 + wave] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_ID
         a.dbg[48] = nsteps;
         if (is_tin && tw < 2) {                       // two T-in waves: phases inside a step
             for (int i = 0; i < 3; i++)
-                a.dbg[49 + 3 * tw + i] = st_p[i];
+                a.dbg[50 + 3 * tw + i] = st_p[i];
         }
+        a.dbg[24 + wave] = role;
     }
 #endif
+
+    // state for the next launch.  y1/y2 of section k are also the x1/x2 of section k+1
+    // (its input is this section's output); section 0's x1/x2 were written by the T lanes.
+    if (has_sec && live) {
+        float *st = a.state[sidx].s[sec];
+        st[2] = h1;
+        st[3] = h2;
+        if (sec + 1u < (u32)NSEC) {
+            float *sn = a.state[sidx].s[sec + 1u];
+            if (my_nfr >= 2u) {
+                sn[0] = h1;
+                sn[1] = h2;
+            } else if (my_nfr == 1u) {
+                sn[1] = sn[0];
+                sn[0] = h1;
+            }
+        }
+    }
 }
 
 template <int NSEC, int G>
 static constexpr size_t eq_pipe_lds_bytes()
 {
-    return ((size_t)(2 * NSEC) * 2 * G * (64 + 4)) * sizeof(float) + G * sizeof(u32) + (size_t)NSEC * G * 2 * sizeof(float);
+    return ((size_t)(2 * NSEC) * 2 * G * (64 + 4)) * sizeof(float) + G * sizeof(u32);
 }
 
 template <int NSEC, int G, int CH>

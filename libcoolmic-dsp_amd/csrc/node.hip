@@ -117,6 +117,7 @@ struct cmhip_node {
     // the whole set at once, when the first block after an exchange arrives; `filled` marks the
     // slots written since.
     std::vector<bool> filled[NODE_SETS];
+    bool side;                             // records are built beside the batch's next run (its copy stream)
 };
 
 static long long *set_sums(const cmhip_node_t *n, unsigned set)
@@ -211,6 +212,7 @@ extern "C" cmhip_node_t *cmhip_node_new(int device, int nranks, int rank, const 
         n->exchanged[i] = false;
         n->filled[i].assign(max_records, false);       // (the buffer starts zeroed)
     }
+    n->side = getenv("CMHIP_NODE_MAIN_STREAM") == nullptr;       // (A/B knob, read once)
     n->device = device;
     n->nranks = nranks;
     n->rank = rank;
@@ -234,7 +236,7 @@ extern "C" int cmhip_node_partial(cmhip_node_t *n, cmhip_batch_t *b, unsigned in
     if (cmhip_batch_device(b) != n->device || !(cmhip_batch_flags(b) & CMHIP_VU))
         return fail(COOLMIC_ERROR_INVAL, "node_partial: the batch must have VU windows on device %d", n->device);
     HIP_TRY(hipSetDevice(n->device));
-    hipStream_t bs = (hipStream_t)cmhip_batch_hip_stream(b);
+    hipStream_t bs = (hipStream_t)(n->side ? cmhip_batch_side_stream(b) : cmhip_batch_hip_stream(b));
     if (n->exchanged[set]) {               // the set's last exchange must be through before it is refilled
         if (hipEventQuery(n->ev_done[set]) != hipSuccess)
             HIP_TRY(hipStreamWaitEvent(bs, n->ev_done[set], 0));
@@ -246,8 +248,11 @@ extern "C" int cmhip_node_partial(cmhip_node_t *n, cmhip_batch_t *b, unsigned in
         HIP_TRY(hipMemsetAsync(set_keys(n, set) + (size_t)slot * HALF, 0, HALF * sizeof(long long), bs));
     }
     n->filled[set][slot] = true;
-    return cmhip_batch_node_partial_split(b, set_sums(n, set) + (size_t)slot * HALF,
-                                          set_keys(n, set) + (size_t)slot * HALF, first_global, global_step, 0);
+    if (!n->side)
+        return cmhip_batch_node_partial_split(b, set_sums(n, set) + (size_t)slot * HALF,
+                                              set_keys(n, set) + (size_t)slot * HALF, first_global, global_step, 0);
+    return cmhip_batch_node_partial_side(b, set_sums(n, set) + (size_t)slot * HALF,
+                                         set_keys(n, set) + (size_t)slot * HALF, first_global, global_step);
 }
 
 extern "C" int cmhip_node_allreduce(cmhip_node_t *n, unsigned int set, unsigned int count, cmhip_batch_t *after)
@@ -259,7 +264,8 @@ extern "C" int cmhip_node_allreduce(cmhip_node_t *n, unsigned int set, unsigned 
     const Rccl *rc = rccl();
     HIP_TRY(hipSetDevice(n->device));
     if (after) {
-        HIP_TRY(hipEventRecord(n->ev_filled, (hipStream_t)cmhip_batch_hip_stream(after)));
+        HIP_TRY(hipEventRecord(n->ev_filled, (hipStream_t)(n->side ? cmhip_batch_side_stream(after)
+                                                                   : cmhip_batch_hip_stream(after))));
         HIP_TRY(hipStreamWaitEvent(n->stream, n->ev_filled, 0));
     }
     // sums of all slots, then keys of all slots: two collectives, one launch (keys are below 2^63

@@ -1,6 +1,6 @@
 #!/bin/bash
 # copies what tools/run_round_checks.sh left under gpurun_out/ into profiles/ (names of round $1, default r01)
-R=${1:-r01}
+R=${1:-r02}
 set -e
 cp gpurun_out/bench_default.json profiles/${R}_bench_default.json
 cp gpurun_out/c2_rocprof.json profiles/${R}_c2_bench_under_rocprof.json
@@ -13,3 +13,11 @@ for w in c2 c3; do
     cp gpurun_out/pmc_$w.json profiles/pmc_$w.json
 done
 cp gpurun_out/pmc_c2.json profiles/pmc_latest.json
+cp gpurun_out/bench_default.json profiles/n1_c2.json
+for w in c3 c4 c5; do
+    cp gpurun_out/n1_$w.json profiles/n1_$w.json
+    cp gpurun_out/n1_$w.json profiles/${R}_${w}_bench_n1.json
+done
+cp gpurun_out/rehearsal_c5_2ranks.json profiles/${R}_rehearsal_c5_2ranks_one_gpu.json
+for t in many_channels eq eq_sections chain; do cp gpurun_out/table_$t.txt profiles/${R}_table_$t.txt; done
+tail -25 gpurun_out/eq_sq_counters.txt > profiles/${R}_c3_sq_counters.txt

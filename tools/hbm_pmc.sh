@@ -31,7 +31,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 rd = raw["FETCH_SIZE"]["mean_KiB"] * 1024 * 2
 wr = raw["WRITE_SIZE"]["mean_KiB"] * 1024
 alg = line["roofline"]["algorithmic_bytes_per_launch"]
-res = {"round": 1, "workload": wl, "streams": line["config"]["streams_per_gpu"], "channels": line["config"]["channels"],
+res = {"round": "round 2", "workload": wl, "streams": line["config"]["streams_per_gpu"], "channels": line["config"]["channels"],
        "frames": line["config"]["frames_per_launch"], "kernel": name,
        "command": "tools/hbm_pmc.sh %s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, one counter per pass, bench.py --steps 5 --warmup 1 --no-cpu --no-extras)" % wl,
        "raw": raw,

@@ -18,3 +18,15 @@ cat $R/gpurun_out/c2_rocprof.json
 cd $R
 timeout -k 10 300 bash tools/hbm_pmc.sh c2 > gpurun_out/hbm_c2.log 2>&1 && tail -8 gpurun_out/hbm_c2.log
 timeout -k 10 300 bash tools/hbm_pmc.sh c3 > gpurun_out/hbm_c3.log 2>&1 && tail -8 gpurun_out/hbm_c3.log
+# the N = 1 lines of the other workloads (config 5 with a one-rank RCCL communicator: all a 1-GPU box holds),
+# the 2-rank rehearsal of the self-launching bench on one GPU, and the tables DESIGN.md quotes
+timeout -k 10 300 python bench.py --workload c4 --no-extras --no-cpu > gpurun_out/n1_c4.json 2> gpurun_out/n1_c4.err
+timeout -k 10 300 env COOLMIC_BENCH_FORCE_NODE=1 python bench.py --workload c5 --no-extras --no-cpu > gpurun_out/n1_c5.json 2> gpurun_out/n1_c5.err
+timeout -k 10 300 python bench.py --workload c3 --no-cpu > gpurun_out/n1_c3.json 2> gpurun_out/n1_c3.err
+timeout -k 10 300 env COOLMIC_BENCH_REHEARSAL=1 python bench.py --gpus 2 --workload c5 --steps 100 --warmup 20 --no-extras --no-cpu > gpurun_out/rehearsal_c5_2ranks.json 2> gpurun_out/rehearsal_c5_2ranks.err
+timeout -k 10 300 python tools/bench_generic.py > gpurun_out/table_many_channels.txt 2>&1
+timeout -k 10 300 python tools/bench_eq.py > gpurun_out/table_eq.txt 2>&1
+timeout -k 10 300 python tools/bench_eq_sections.py > gpurun_out/table_eq_sections.txt 2>&1
+timeout -k 10 120 python tools/bench_chain.py > gpurun_out/table_chain.txt 2>&1
+timeout -k 10 900 bash tools/eq_pmc.sh > gpurun_out/eq_sq_counters.txt 2>&1
+tail -25 gpurun_out/eq_sq_counters.txt
