@@ -56,6 +56,31 @@ __device__ __forceinline__ int f32_to_i16(float y)
 #ifndef CMHIP_EQ_ABL
 #define CMHIP_EQ_ABL 0            // `make abl`: timing-only builds with one part of the pipeline cut out
 #endif
+// Sensitivity builds (`make variant NAME=pad_r DEFS=-DCMHIP_EQ_PAD_R=32`, tools/ab_two_libs.py): N extra
+// VALU instructions per step in the waves of one role.  What the launch time gains per padded
+// instruction says which role the step waits for.  Never defined in the product.
+#ifndef CMHIP_EQ_PAD_R
+#define CMHIP_EQ_PAD_R 0
+#endif
+#ifndef CMHIP_EQ_PAD_TIN
+#define CMHIP_EQ_PAD_TIN 0
+#endif
+#ifndef CMHIP_EQ_PAD_TFF
+#define CMHIP_EQ_PAD_TFF 0
+#endif
+#ifndef CMHIP_EQ_PAD_S
+#define CMHIP_EQ_PAD_S 0
+#endif
+template <int N>
+__device__ __forceinline__ void eq_pad()
+{
+    if constexpr (N > 0) {
+        u32 t = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            asm volatile("v_add_u32 %0, %0, %0" : "+v"(t));
+    }
+}
 
 // Channels: a "row" is one channel of one stream -- every channel runs its stream's filter
 // with state of its own -- and a workgroup takes G / C whole streams.  CH = 1: mono, the 16-byte
@@ -315,6 +340,7 @@ void k_eq_pipe(EqArgs a)
     // (Loading an R wave's next row into registers a step ahead was worth 7 % with eight waves
     // per workgroup; with twelve it needs more registers than three waves per SIMD leave.)
     auto rec_step = [&](const u32 step) {
+        eq_pad<CMHIP_EQ_PAD_R>();
         if (!(CMHIP_EQ_ABL & 32)) {
             const u32 first = HOP * sec + HOP - 1u;       // step in which block 0 is worked on
             const u32 b = step - first;
@@ -370,6 +396,7 @@ void k_eq_pipe(EqArgs a)
     float keep1 = 0.f, keep2 = 0.f;                       // section 0's new x1 / x2, if seen
     bool has1 = false, has2 = false;
     auto tin_step = [&](Pcm &wcur, const u32 step) {
+        eq_pad<CMHIP_EQ_PAD_TIN>();
         if (!(CMHIP_EQ_ABL & 128)) {
 #ifdef CMHIP_EQ_STAMPS
             const u64 st_tt = __builtin_readcyclecounter();
@@ -468,6 +495,7 @@ void k_eq_pipe(EqArgs a)
     // T-ff waves: feed-forward of the later sections, Y_k-1 -> F_k, for G / 2 rows in PASSES of
     // eight (each with the history registers of its own rows)
     auto tff_step = [&](const u32 step) {
+        eq_pad<CMHIP_EQ_PAD_TFF>();
         if (!(CMHIP_EQ_ABL & (128 | 16))) {
             // reads of every pass first, then arithmetic: one LDS latency per step
             constexpr u32 PG = PASSES;
@@ -530,6 +558,7 @@ void k_eq_pipe(EqArgs a)
             vbase[i] = a.vu[v_stream[i]].samples[a.parity];
     }
     auto s_step = [&](const u32 step) {
+        eq_pad<CMHIP_EQ_PAD_S>();
         if (!(CMHIP_EQ_ABL & 1)) {
             // --- the finished block of the last section leaves: 256 B (float) / 128 B (int16)
             // per stream row and instruction, fire and forget (this wave never waits for
