@@ -43,6 +43,7 @@ typedef struct cmhip_batch cmhip_batch_t;
 #define CMHIP_EQ           0x0010u   /* biquad EQ after map and gain, every channel with state of its own */
 #define CMHIP_HOSTPCM      0x0020u   /* PCM slots in pinned host memory the kernels access directly (zero copy):
                                       * for small batches fed block by block, e.g. the per-stream stages */
+#define CMHIP_EXTSLOTS     0x0040u   /* no PCM slots of its own: every run names them (cmhip_batch_run_slots) */
 
 /* synthetic inputs generated on the device */
 #define CMHIP_GEN_NULL     0         /* zeros, as snddev "null" */
@@ -106,6 +107,8 @@ int cmhip_batch_download(cmhip_batch_t *b, unsigned int stream, int16_t *pcm, si
 int   cmhip_batch_upload_all(cmhip_batch_t *b, const int16_t *host, size_t frames);
 int   cmhip_batch_download_all(cmhip_batch_t *b, int16_t *host, size_t frames);
 void *cmhip_host_alloc(size_t bytes);             /* NULL on failure */
+/* pinned and mapped into the device: the host uses the returned pointer, kernels *device_ptr */
+void *cmhip_host_alloc_mapped(size_t bytes, void **device_ptr);
 void  cmhip_host_free(void *p);
 /* reads an input slot back (generated or uploaded PCM); synchronises */
 int cmhip_batch_download_input(cmhip_batch_t *b, unsigned int stream, int16_t *pcm, size_t frames);
@@ -120,6 +123,13 @@ int cmhip_batch_generate(cmhip_batch_t *b, int mode, uint32_t seed, size_t frame
 /* process `frames` frames of every stream (frames_per_stream, if not NULL, gives each
  * stream its own count <= frames; host array of S entries).  Asynchronous. */
 int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per_stream);
+/* the same pass over PCM arrays named for this run: device-accessible memory laid out like the
+ * batch's own, int16 [S][cmhip_batch_stride()] (slots_out NULL exactly when the batch writes no
+ * PCM, == slots_in for CMHIP_INPLACE).  With pinned, device-mapped host memory
+ * (cmhip_host_alloc_mapped) the kernel moves the block over PCIe itself, and a host can rotate
+ * several sets: sources fill one, readers drain another, a third is on the GPU. */
+int cmhip_batch_run_slots(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per_stream,
+                          const void *slots_in, void *slots_out);
 int cmhip_batch_sync(cmhip_batch_t *b);
 
 /* ---- VU windows ------------------------------------------------------------ */

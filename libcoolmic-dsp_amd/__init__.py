@@ -29,7 +29,7 @@ ssize_t = C.c_ssize_t
 ERROR_NONE, ERROR_GENERIC, ERROR_NOSYS, ERROR_FAULT = 0, -1, -8, -9
 ERROR_INVAL, ERROR_NOMEM, ERROR_BUSY = -10, -11, -12
 
-OUT_PCM, OUT_F32, VU, INPLACE, EQ, HOSTPCM = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+OUT_PCM, OUT_F32, VU, INPLACE, EQ, HOSTPCM, EXTSLOTS = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40
 GEN_NULL, GEN_SINE, GEN_NOISE = 0, 1, 2
 NODE_WORDS = 34
 
@@ -108,6 +108,8 @@ SIGNATURES = {
     "cmhip_batch_vu_raw": (C.c_int, [_vp, C.c_uint, _vp, _vp, _P(C.c_uint64)]),
     "cmhip_batch_vu_node_partial": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64]),
     "cmhip_node_finish": (C.c_int, [_vp, C.c_uint, C.c_uint, _P(VuResult)]),
+    "cmhip_batch_run_slots": (C.c_int, [_vp, C.c_size_t, _vp, _vp, _vp]),
+    "cmhip_host_alloc_mapped": (_vp, [C.c_size_t, _P(_vp)]),
     "cmhip_node_unique_id": (C.c_int, [_vp]),
     "cmhip_node_new": (_vp, [C.c_int, C.c_int, C.c_int, _vp, C.c_uint]),
     "cmhip_node_free": (None, [_vp]),
@@ -321,6 +323,13 @@ class Batch:
             assert a.size == self.streams
             _check("run", lib.cmhip_batch_run(self.h, frames, a.ctypes.data))
 
+    def run_slots(self, frames, slots_in, slots_out, frames_per_stream=None):
+        """one pass over PCM arrays named for this run (device pointers; MappedPcm.dev)"""
+        fps = None
+        if frames_per_stream is not None:
+            fps = (C.c_uint32 * self.streams)(*frames_per_stream)
+        _check("run_slots", lib.cmhip_batch_run_slots(self.h, frames, fps, slots_in, slots_out))
+
     def hip_stream(self):
         """the hipStream_t (as an integer) this batch launches on"""
         return lib.cmhip_batch_hip_stream(self.h) or 0
@@ -398,6 +407,28 @@ class PinnedPcm:
         self.ptr = lib.cmhip_host_alloc(self.nbytes)
         if not self.ptr:
             raise CoolmicError("cmhip_host_alloc", ERROR_NOMEM)
+        buf = (C.c_int16 * (self.nbytes // 2)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=np.int16).reshape(self.shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib.cmhip_host_free(self.ptr)
+            self.ptr = None
+
+
+class MappedPcm:
+    """pinned, device-mapped host mirror of a batch's slot layout: numpy view int16 [S][stride] on the
+    host, `.dev` for cmhip_batch_run_slots"""
+
+    def __init__(self, batch):
+        self.shape = (batch.streams, batch.stride)
+        self.nbytes = batch.streams * batch.stride * 2
+        dev = C.c_void_p()
+        self.ptr = lib.cmhip_host_alloc_mapped(self.nbytes, C.byref(dev))
+        if not self.ptr:
+            raise CoolmicError("cmhip_host_alloc_mapped", ERROR_NOMEM)
+        self.dev = dev.value
         buf = (C.c_int16 * (self.nbytes // 2)).from_address(self.ptr)
         self.array = np.frombuffer(buf, dtype=np.int16).reshape(self.shape)
 

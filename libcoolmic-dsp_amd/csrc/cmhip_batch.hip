@@ -302,7 +302,9 @@ static int batch_init(cmhip_batch_t *b)
     b->plane = (d.max_frames + 63) / 64 * 64;
 
     const size_t pcm_bytes = S * b->stride * sizeof(int16_t);
-    if (d.flags & CMHIP_HOSTPCM) {
+    if (d.flags & CMHIP_EXTSLOTS) {
+        // no PCM arrays of its own: every run names them (cmhip_batch_run_slots)
+    } else if (d.flags & CMHIP_HOSTPCM) {
         // zero copy: the kernels read and write pinned, device-mapped host memory; an upload or
         // download is a memcpy on the host (for the 1 KiB blocks of the per-stream stages the
         // two DMA submissions cost more than the block itself)
@@ -649,8 +651,8 @@ extern "C" int cmhip_batch_upload(cmhip_batch_t *b, unsigned int stream, const i
 {
     if (!b || !pcm)
         return fail(COOLMIC_ERROR_FAULT, "upload: NULL argument");
-    if (stream >= b->d.streams || frames > b->d.max_frames)
-        return fail(COOLMIC_ERROR_INVAL, "upload: stream or frames out of range");
+    if (stream >= b->d.streams || frames > b->d.max_frames || !b->d_in)
+        return fail(COOLMIC_ERROR_INVAL, "upload: stream or frames out of range (or a batch without slots of its own)");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     const size_t bytes = frames * b->d.channels * sizeof(int16_t);
@@ -689,8 +691,8 @@ extern "C" int cmhip_batch_upload_all(cmhip_batch_t *b, const int16_t *host, siz
 {
     if (!b || !host)
         return fail(COOLMIC_ERROR_FAULT, "upload_all: NULL argument");
-    if (frames == 0 || frames > b->d.max_frames)
-        return fail(COOLMIC_ERROR_INVAL, "upload_all: frames out of range");
+    if (frames == 0 || frames > b->d.max_frames || !b->d_in)
+        return fail(COOLMIC_ERROR_INVAL, "upload_all: frames out of range (or a batch without slots of its own)");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     const size_t span = ((size_t)(b->d.streams - 1) * b->stride + frames * b->d.channels) * sizeof(int16_t);
@@ -736,6 +738,24 @@ extern "C" void *cmhip_host_alloc(size_t bytes)
     return p;
 }
 
+// pinned AND mapped into the device's address space: *device_ptr is what kernels (and
+// cmhip_batch_run_slots) take for the memory the host reaches through the returned pointer
+extern "C" void *cmhip_host_alloc_mapped(size_t bytes, void **device_ptr)
+{
+    void *p = nullptr;
+    if (!device_ptr || hipHostMalloc(&p, bytes, hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(COOLMIC_ERROR_NOMEM, "cmhip_host_alloc_mapped: %zu bytes of mapped pinned memory", bytes);
+        return nullptr;
+    }
+    if (hipHostGetDevicePointer(device_ptr, p, 0) != hipSuccess) {
+        (void)hipHostFree(p);
+        fail(COOLMIC_ERROR_GENERIC, "cmhip_host_alloc_mapped: no device pointer");
+        return nullptr;
+    }
+    return p;
+}
+
 extern "C" void cmhip_host_free(void *p)
 {
     if (p)
@@ -771,8 +791,8 @@ extern "C" int cmhip_batch_download_input(cmhip_batch_t *b, unsigned int stream,
 {
     if (!b || !pcm)
         return fail(COOLMIC_ERROR_FAULT, "download_input: NULL argument");
-    if (stream >= b->d.streams || frames > b->d.max_frames)
-        return fail(COOLMIC_ERROR_INVAL, "download_input: stream or frames out of range");
+    if (stream >= b->d.streams || frames > b->d.max_frames || !b->d_in)
+        return fail(COOLMIC_ERROR_INVAL, "download_input: stream or frames out of range (or a batch without slots of its own)");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     if (b->h_in) {
@@ -811,8 +831,8 @@ extern "C" int cmhip_batch_generate(cmhip_batch_t *b, int mode, uint32_t seed, s
 {
     if (!b)
         return fail(COOLMIC_ERROR_FAULT, "generate: batch is NULL");
-    if (frames > b->d.max_frames || mode < 0 || mode > 2)
-        return fail(COOLMIC_ERROR_INVAL, "generate: frames or mode out of range");
+    if (frames > b->d.max_frames || mode < 0 || mode > 2 || !b->d_in)
+        return fail(COOLMIC_ERROR_INVAL, "generate: frames or mode out of range (or a batch without slots of its own)");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     GenArgs g;
@@ -886,10 +906,38 @@ static EventPair take_events(cmhip_batch_t *b)
     return e;
 }
 
+static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per_stream, const int16_t *slots_in,
+                     int16_t *slots_out);
+
 extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per_stream)
 {
     if (!b)
         return fail(COOLMIC_ERROR_FAULT, "run: batch is NULL");
+    if (!b->d_in)
+        return fail(COOLMIC_ERROR_INVAL, "run: this batch has no slots of its own (cmhip_batch_run_slots)");
+    return batch_run(b, frames, frames_per_stream, b->d_in, b->d_out);
+}
+
+// The same pass over PCM arrays the caller names for this run: device-accessible memory laid out
+// like the batch's own, [S][cmhip_batch_stride()] -- e.g. pinned, device-mapped host memory from
+// cmhip_host_alloc_mapped(), which the kernel then reads and writes over PCIe (coolmic_group_t
+// rotates several such sets so that sources fill one and readers drain another while a third is
+// on the GPU).  Parameters, VU windows and filter state are the batch's, as ever.
+extern "C" int cmhip_batch_run_slots(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per_stream,
+                                     const void *slots_in, void *slots_out)
+{
+    if (!b || !slots_in)
+        return fail(COOLMIC_ERROR_FAULT, "run_slots: NULL argument");
+    if (((b->d.flags & CMHIP_OUT_PCM) != 0) != (slots_out != nullptr))
+        return fail(COOLMIC_ERROR_INVAL, "run_slots: an output array exactly when the batch writes PCM");
+    if ((b->d.flags & CMHIP_INPLACE) && slots_out != slots_in)
+        return fail(COOLMIC_ERROR_INVAL, "run_slots: an in-place batch takes the same array twice");
+    return batch_run(b, frames, frames_per_stream, (const int16_t *)slots_in, (int16_t *)slots_out);
+}
+
+static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per_stream, const int16_t *slots_in,
+                     int16_t *slots_out)
+{
     if (frames > b->d.max_frames)
         return fail(COOLMIC_ERROR_INVAL, "run: %zu frames exceed the slot capacity %zu", frames,
                     b->d.max_frames);
@@ -919,8 +967,8 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
     if ((b->d.flags & CMHIP_EQ) && b->nsec) {        // without sections the plain kernels do the same
         EqArgs a;
         memset(&a, 0, sizeof(a));
-        a.in = b->d_in;
-        a.out = (b->d.flags & CMHIP_OUT_PCM) ? b->d_out : nullptr;
+        a.in = slots_in;
+        a.out = (b->d.flags & CMHIP_OUT_PCM) ? slots_out : nullptr;
         a.f32 = b->d_f32;
         a.param = b->d_param;
         a.eq = b->d_eq;
@@ -931,7 +979,7 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
         a.streams = b->d.streams;
         a.channels = b->d.channels;
         a.nsec = b->nsec;
-        a.whole_streams = (b->d_out == b->d_in && !b->all_identity) ? 1u : 0u;
+        a.whole_streams = (slots_out == slots_in && !b->all_identity) ? 1u : 0u;
         a.parity = b->parity;
         a.dbg = b->d_dbg;
         a.stride = b->stride;
@@ -941,8 +989,8 @@ extern "C" int cmhip_batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *
     } else {
         RunArgs a;
         memset(&a, 0, sizeof(a));
-        a.in = b->d_in;
-        a.out = (b->d.flags & CMHIP_OUT_PCM) ? b->d_out : nullptr;
+        a.in = slots_in;
+        a.out = (b->d.flags & CMHIP_OUT_PCM) ? slots_out : nullptr;
         a.f32 = b->d_f32;
         a.param = b->d_param;
         a.gshort = b->d_gshort;

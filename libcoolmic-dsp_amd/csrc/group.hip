@@ -5,21 +5,34 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <deque>
 #include <vector>
-
-#include "work_pool.h"
 
 #define COOLMIC_COMPONENT "libcoolmic-dsp/group"
 #include "host_internal.h"
 #include <coolmic-dsp/group.h>
 #include <coolmic_hip.h>
 
+// A block's PCM never leaves the pinned set it was produced in until a reader copies it out: the
+// batch has no PCM arrays of its own (CMHIP_EXTSLOTS); the group owns two input sets and a ring of
+// output sets in pinned, device-mapped host memory, and every launch reads one and writes one over
+// PCIe (cmhip_batch_run_slots).  Sources write straight into the set the kernel will read; readers
+// read straight from the set the kernel wrote.  (Round 1 copied host -> device -> host with the copy
+// engines and then every block once more into a per-stream queue: the host's memory traffic, not the
+// GPU, set the rate.)
+struct GroupSeg {                            // a stream's share of one block, still in its output set
+    unsigned int set;
+    uint32_t bytes, pos;
+};
+
 struct GroupStream {
     coolmic_iohandle_t *source;
     unsigned char carry[2 * COOLMIC_DSP_VUMETER_MAX_CHANNELS - 1];   // partial input frame
     size_t carry_fill;
-    std::vector<unsigned char> queue;        // processed PCM not yet read, whole frames
-    size_t queue_pos;                        // bytes already handed out
+    std::deque<GroupSeg> segs;               // processed PCM not yet read, oldest first
+    std::vector<unsigned char> spill;        // ... and what had to leave a set that was needed again
+    size_t spill_pos;                        //     (older than every segment)
+    size_t pending;                          // bytes in spill and segments together
 };
 
 struct coolmic_group {
@@ -28,14 +41,19 @@ struct coolmic_group {
     unsigned int channels, max_streams, queue_blocks;
     size_t block_frames;
     cmhip_batch_t *batch;
-    int16_t *h_in[2], *h_out;                // pinned mirrors of the batch's PCM slots (input: two sets)
+    int16_t *h_in[2];                        // input sets, host view
+    void *d_in[2];                           // ... device view
+    std::vector<int16_t *> *h_out;           // ring of output sets (queue_blocks + 2), host view
+    std::vector<void *> *d_out;
+    std::vector<unsigned int> *out_users;    // streams with unread bytes in a set
+    unsigned int out_next;                   // set the next block is written to
+    unsigned int flight_set;                 // set of the block on the GPU
     unsigned int cur;                        // input set the next pull fills
     size_t stride;                           // samples between slots
     std::vector<GroupStream> *streams;
     std::vector<uint32_t> *nframes;          // frames per stream of the block being pulled
     std::vector<uint32_t> *flight;           // ... of the block on the GPU
-    bool in_flight;                          // upload + launch + download of a block are queued
-    WorkPool *pool;                          // helpers for the queue copies of large groups
+    bool in_flight;                          // a block's launch is queued
 };
 
 struct GroupHandle {
@@ -53,15 +71,17 @@ static void group_destroy(void *self)
     }
     delete g->nframes;
     delete g->flight;
-    delete g->pool;
-    if (g->in_flight)                        // the copies of the last block still use the staging
-        (void)hipStreamSynchronize((hipStream_t)cmhip_batch_hip_stream(g->batch));
-    for (int i = 0; i < 2; i++)
-        if (g->h_in[i])
-            (void)hipHostFree(g->h_in[i]);
-    if (g->h_out)
-        (void)hipHostFree(g->h_out);
+    if (g->in_flight && g->batch)            // the last block's kernel still uses the sets
+        (void)cmhip_batch_sync(g->batch);
     cmhip_batch_free(g->batch);
+    for (int i = 0; i < 2; i++)
+        cmhip_host_free(g->h_in[i]);
+    if (g->h_out)
+        for (int16_t *p : *g->h_out)
+            cmhip_host_free(p);
+    delete g->h_out;
+    delete g->d_out;
+    delete g->out_users;
 }
 
 static const coolmic_ro_type_t group_type = {"coolmic_group_t", sizeof(coolmic_group_t), group_destroy};
@@ -90,7 +110,7 @@ extern "C" coolmic_group_t *coolmic_group_new(const char *name, igloo_ro_t assoc
     d.channels = channels;
     d.rate = (unsigned int)rate;
     d.max_frames = block_frames;
-    d.flags = CMHIP_OUT_PCM | CMHIP_VU | CMHIP_EQ;     // the equaliser is off until coolmic_group_set_eq()
+    d.flags = CMHIP_OUT_PCM | CMHIP_VU | CMHIP_EQ | CMHIP_EXTSLOTS;    // the equaliser is off until coolmic_group_set_eq()
     g->batch = cmhip_batch_new(&d);
     if (!g->batch) {
         coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_NOSYS,
@@ -101,16 +121,27 @@ extern "C" coolmic_group_t *coolmic_group_new(const char *name, igloo_ro_t assoc
     }
     g->stride = cmhip_batch_stride(g->batch);
     const size_t bytes = (size_t)max_streams * g->stride * sizeof(int16_t);
-    if (hipHostMalloc((void **)&g->h_in[0], bytes, hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&g->h_in[1], bytes, hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&g->h_out, bytes, hipHostMallocDefault) != hipSuccess) {
+    const unsigned nout = g->queue_blocks + 2u;          // one on the GPU, queue_blocks being read, one spare
+    g->h_out = new std::vector<int16_t *>(nout, nullptr);
+    g->d_out = new std::vector<void *>(nout, nullptr);
+    g->out_users = new std::vector<unsigned int>(nout, 0);
+    bool ok = true;
+    for (int i = 0; i < 2 && ok; i++) {
+        g->h_in[i] = (int16_t *)cmhip_host_alloc_mapped(bytes, &g->d_in[i]);
+        ok = g->h_in[i] != nullptr;
+        if (ok)
+            memset(g->h_in[i], 0, bytes);
+    }
+    for (unsigned i = 0; i < nout && ok; i++) {
+        (*g->h_out)[i] = (int16_t *)cmhip_host_alloc_mapped(bytes, &(*g->d_out)[i]);
+        ok = (*g->h_out)[i] != nullptr;
+    }
+    if (!ok) {
         coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_NOMEM,
-                            "pinned staging of %zu bytes x 3 failed", bytes);
+                            "pinned, device-mapped PCM sets of %zu bytes x %u failed", bytes, nout + 2u);
         coolmic_ro_unref(g);
         return NULL;
     }
-    memset(g->h_in[0], 0, bytes);
-    memset(g->h_in[1], 0, bytes);
     g->streams = new std::vector<GroupStream>();
     g->streams->reserve(max_streams);
     g->nframes = new std::vector<uint32_t>(max_streams, 0);
@@ -132,7 +163,8 @@ extern "C" int coolmic_group_add_stream(coolmic_group_t *self, coolmic_iohandle_
     GroupStream s;
     s.source = source;
     s.carry_fill = 0;
-    s.queue_pos = 0;
+    s.spill_pos = 0;
+    s.pending = 0;
     coolmic_ro_ref(source);
     self->streams->push_back(std::move(s));
     return (int)self->streams->size() - 1;
@@ -172,64 +204,60 @@ extern "C" int coolmic_group_set_eq(coolmic_group_t *self, int slot, unsigned in
     return rc;
 }
 
-// The block on the GPU comes home: wait for its download and hand the PCM to the streams' queues.
-// With many streams the copies are shared out over a few helper threads (streams are independent).
+// The block on the GPU comes home: wait for its launch; every stream gets a segment in the set the
+// kernel wrote (nothing is copied).
 static int group_complete(coolmic_group_t *self)
 {
     if (!self->in_flight)
         return COOLMIC_ERROR_NONE;
     self->in_flight = false;
-    if (hipStreamSynchronize((hipStream_t)cmhip_batch_hip_stream(self->batch)) != hipSuccess) {
+    if (cmhip_batch_sync(self->batch) != COOLMIC_ERROR_NONE) {
         coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_GENERIC,
                             "HIP group block failed: %s", cmhip_last_error());
         return COOLMIC_ERROR_GENERIC;
     }
     const size_t n = self->streams->size();
-    const size_t framesize = 2u * self->channels;
-    const size_t queue_cap = self->block_frames * framesize * self->queue_blocks;
-    struct Job {
-        coolmic_group_t *g;
-        size_t framesize, queue_cap;
-    } job = {self, framesize, queue_cap};
-    auto body = [](void *p, unsigned lo, unsigned hi) {
-        Job *j = (Job *)p;
-        coolmic_group_t *g = j->g;
-        for (unsigned i = lo; i < hi; i++) {
-            const uint32_t fr = (*g->flight)[i];
-            if (!fr)
-                continue;
-            (*g->flight)[i] = 0;
-            GroupStream &s = (*g->streams)[i];
-            if (s.queue_pos == s.queue.size()) {
-                s.queue.clear();
-                s.queue_pos = 0;
-            } else if (s.queue_pos > j->queue_cap) {
-                s.queue.erase(s.queue.begin(), s.queue.begin() + (ptrdiff_t)s.queue_pos);
-                s.queue_pos = 0;
-            }
-            const unsigned char *src = (const unsigned char *)(g->h_out + i * g->stride);
-            s.queue.insert(s.queue.end(), src, src + (size_t)fr * j->framesize);
-        }
-    };
-    size_t bytes = 0;
-    for (size_t i = 0; i < n; i++)
-        bytes += (size_t)(*self->flight)[i] * framesize;
-    if (bytes >= (4u << 20) && n >= 64) {            // worth waking helpers for
-        if (!self->pool) {
-            unsigned t = std::thread::hardware_concurrency() / 2;
-            self->pool = new WorkPool(t < 1 ? 1 : (t > 6 ? 6 : t));
-        }
-        self->pool->run(body, &job, (unsigned)n, (unsigned)(n / 32 ? n / 32 : 1));
-    } else {
-        body(&job, 0, (unsigned)n);
+    const uint32_t framesize = 2u * self->channels;
+    const unsigned set = self->flight_set;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t fr = (*self->flight)[i];
+        if (!fr)
+            continue;
+        (*self->flight)[i] = 0;
+        GroupStream &s = (*self->streams)[i];
+        s.segs.push_back(GroupSeg{set, fr * framesize, 0});
+        s.pending += (size_t)fr * framesize;
+        (*self->out_users)[set]++;
     }
     return COOLMIC_ERROR_NONE;
 }
 
-// One block: pull from every source into pinned staging, then (the previous block being home)
-// queue upload, launch and download of this one and return -- the GPU and the copies work while
-// the caller reads the queues and the next pump pulls.  The block's PCM reaches the queues with
-// the next pump, or with the first read that finds a queue empty.
+// An output set is needed again while a slow reader still has bytes in it: they move to the
+// stream's own spill buffer (sets are used in ring order, so it is the stream's oldest segment).
+static void group_vacate(coolmic_group_t *self, unsigned set)
+{
+    if ((*self->out_users)[set] == 0)
+        return;
+    for (size_t i = 0; i < self->streams->size(); i++) {
+        GroupStream &s = (*self->streams)[i];
+        if (s.segs.empty() || s.segs.front().set != set)
+            continue;
+        const GroupSeg g = s.segs.front();
+        s.segs.pop_front();
+        if (s.spill_pos == s.spill.size()) {
+            s.spill.clear();
+            s.spill_pos = 0;
+        }
+        const unsigned char *src = (const unsigned char *)((*self->h_out)[set] + i * self->stride) + g.pos;
+        s.spill.insert(s.spill.end(), src, src + (g.bytes - g.pos));
+    }
+    (*self->out_users)[set] = 0;
+}
+
+// One block: pull from every source straight into the input set the kernel will read, then (the
+// previous block being home) launch this one on that set and the next output set, and return --
+// the GPU works while the caller reads and the next pump pulls.  The block's PCM can be read with
+// the next pump, or with the first read that finds a stream empty.
 extern "C" int coolmic_group_pump(coolmic_group_t *self)
 {
     if (!self)
@@ -249,7 +277,7 @@ extern "C" int coolmic_group_pump(coolmic_group_t *self)
         GroupStream &s = (*self->streams)[i];
         (*self->nframes)[i] = 0;
         const size_t coming = self->in_flight ? (size_t)(*self->flight)[i] * framesize : 0;
-        if (s.queue.size() - s.queue_pos + coming + block_bytes > queue_cap)
+        if (s.pending + coming + block_bytes > queue_cap)
             continue;                          // this stream's reader is behind: no read-ahead
         unsigned char *dst = (unsigned char *)(h_in + i * self->stride);
         size_t have = 0;
@@ -275,27 +303,27 @@ extern "C" int coolmic_group_pump(coolmic_group_t *self)
             delivered++;
     }
 
-    // 2. the block before this one: its download was queued a pump ago
+    // 2. the block before this one
     if (group_complete(self) != COOLMIC_ERROR_NONE)
         return COOLMIC_ERROR_GENERIC;
     if (most == 0)
         return 0;
 
-    // 3. one upload, one launch, one download for the whole group, all queued on the batch's stream
-    hipStream_t st = (hipStream_t)cmhip_batch_hip_stream(self->batch);
-    const size_t span = ((n - 1) * self->stride + (size_t)most * self->channels) * sizeof(int16_t);
-    if (hipMemcpyAsync(cmhip_batch_dev_in(self->batch), h_in, span, hipMemcpyHostToDevice, st) !=
-            hipSuccess ||
-        cmhip_batch_run(self->batch, most, self->nframes->data()) != COOLMIC_ERROR_NONE ||
-        hipMemcpyAsync(self->h_out, cmhip_batch_dev_out(self->batch), span, hipMemcpyDeviceToHost, st) !=
-            hipSuccess) {
+    // 3. one launch for the whole group: the kernel reads this input set and writes the next
+    //    output set, both in host memory, over PCIe
+    const unsigned set = self->out_next;
+    group_vacate(self, set);
+    if (cmhip_batch_run_slots(self->batch, most, self->nframes->data(), self->d_in[self->cur],
+                              (*self->d_out)[set]) != COOLMIC_ERROR_NONE) {
         coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_GENERIC,
                             "HIP group block failed: %s", cmhip_last_error());
-        (void)hipStreamSynchronize(st);
+        (void)cmhip_batch_sync(self->batch);
         return COOLMIC_ERROR_GENERIC;
     }
     std::swap(self->nframes, self->flight);
     self->in_flight = true;
+    self->flight_set = set;
+    self->out_next = (set + 1u) % (unsigned)self->h_out->size();
     self->cur ^= 1u;
     return delivered;
 }
@@ -306,33 +334,50 @@ static ssize_t group_handle_read(void *userdata, void *buffer, size_t len)
     coolmic_group_t *g = h->group;
     GroupStream &s = (*g->streams)[h->slot];
     const size_t framesize = 2u * g->channels;
+    unsigned char *dst = (unsigned char *)buffer;
 
     len -= len % framesize;
     if (len == 0)
         return 0;
-    if (s.queue_pos == s.queue.size()) {         // nothing buffered: the block on the GPU, else a new one
+    if (s.pending == 0) {                        // nothing waiting: the block on the GPU, else a new one
         if (group_complete(g) != COOLMIC_ERROR_NONE)
             return -1;
-        if (s.queue_pos == s.queue.size()) {
+        if (s.pending == 0) {
             if (coolmic_group_pump(g) < 0 || group_complete(g) != COOLMIC_ERROR_NONE)
                 return -1;
         }
     }
-    size_t avail = s.queue.size() - s.queue_pos;
-    if (avail > len)
-        avail = len;
-    if (avail) {
-        memcpy(buffer, s.queue.data() + s.queue_pos, avail);
-        s.queue_pos += avail;
+    size_t done = 0;
+    if (s.spill_pos < s.spill.size()) {          // what left its set early comes first
+        size_t k = s.spill.size() - s.spill_pos;
+        if (k > len)
+            k = len;
+        memcpy(dst, s.spill.data() + s.spill_pos, k);
+        s.spill_pos += k;
+        done = k;
     }
-    return (ssize_t)avail;
+    while (done < len && !s.segs.empty()) {
+        GroupSeg &seg = s.segs.front();
+        size_t k = seg.bytes - seg.pos;
+        if (k > len - done)
+            k = len - done;
+        memcpy(dst + done, (const unsigned char *)((*g->h_out)[seg.set] + (size_t)h->slot * g->stride) + seg.pos, k);
+        seg.pos += (uint32_t)k;
+        done += k;
+        if (seg.pos == seg.bytes) {
+            (*g->out_users)[seg.set]--;
+            s.segs.pop_front();
+        }
+    }
+    s.pending -= done;
+    return (ssize_t)done;
 }
 
 static int group_handle_eof(void *userdata)
 {
     GroupHandle *h = (GroupHandle *)userdata;
     GroupStream &s = (*h->group->streams)[h->slot];
-    if (s.queue_pos != s.queue.size())
+    if (s.pending)
         return 0;
     if (h->group->in_flight && (*h->group->flight)[h->slot])
         return 0;                              // frames of this stream are on their way

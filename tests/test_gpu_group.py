@@ -144,3 +144,49 @@ def test_group_equaliser(gpu, oracle):
     for h in handles:
         h.unref()
     grp.unref()
+
+
+def test_group_slow_readers_and_small_blocks(gpu, oracle):
+    """The processed PCM stays in the pinned set the kernel wrote until a reader takes it; sets are
+    reused in ring order.  Readers of very different pace, sources that deliver a few bytes per pull
+    (many small segments), a queue of one block: every byte still arrives once and in order, and the
+    VU windows are those of the whole streams."""
+    cm = gpu
+    C, N, block = 2, 6, 256
+    grp = cm.Group(C, 8, block, queue_blocks=1)
+    xs, handles = [], []
+    for i in range(N):
+        x = oracle.lcg(7100 + i, (3000 + 517 * i) * C)
+        src = cm.IoHandle.from_bytes(x.tobytes(), chunk=[0, 5, 64, 0, 1000, 3][i])
+        slot = grp.add_stream(src)
+        src.unref()
+        assert grp.set_master_gain(slot, C, 1000, [900, 1100]) == 0
+        xs.append(x)
+        handles.append(grp.get_iohandle(slot))
+    got = [b"" for _ in range(N)]
+    active = set(range(N))
+    rounds = 0
+    while active and rounds < 200000:
+        rounds += 1
+        for i in list(active):
+            if i >= 3 and rounds % (7 * i) != 0:       # the last three readers come rarely ...
+                if rounds % 3 == 0:
+                    grp.pump()                          # ... while the host keeps pumping
+                continue
+            n, data = handles[i].read([4096, 4, 100000, 8, 512, 2048][i])
+            assert n >= 0 and n % (2 * C) == 0
+            got[i] += data
+            if n == 0 and handles[i].eof() == 1:
+                active.discard(i)
+    assert not active
+    for i in range(N):
+        want = _expect(oracle, xs[i], C, [900, 1100], None)
+        assert np.array_equal(np.frombuffer(got[i], np.int16), want), i
+        rc, r = grp.vumeter_result(i)
+        v = oracle.vu_new(C)
+        oracle.vu_accumulate(v, want)
+        _, r_o = oracle.vu_result(v)
+        assert rc == 0 and r.as_dict() == of.vu_result_dict(r_o), i
+    for h in handles:
+        h.unref()
+    grp.unref()

@@ -868,3 +868,46 @@ def test_random_sessions_match_per_stream_oracle(gpu, oracle, C):
                     assert windows[s].result.frames == 0
                     oracle.lib.oracle_vumeter_reset(windows[s])
     b.close()
+
+
+def test_run_on_slot_arrays_named_per_run(gpu, oracle):
+    """cmhip_batch_run_slots: a batch without PCM arrays of its own (CMHIP_EXTSLOTS) runs on pinned,
+    device-mapped host arrays named per run -- two input sets and two output sets in rotation, the VU
+    window and the parameters staying with the batch -- and the entries that need own slots say so"""
+    cm = gpu
+    C, T, S = 2, 3000, 19
+    b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU | cm.EXTSLOTS)
+    assert b.set_gain(-1, 2, 1000, [750, 1250]) == 0
+    assert b.set_chmap(3, [1, 0]) == 0
+    ins = [cm.MappedPcm(b), cm.MappedPcm(b)]
+    outs = [cm.MappedPcm(b), cm.MappedPcm(b)]
+    rng = np.random.default_rng(5)
+    wants = [[] for _ in range(S)]
+    for k in range(4):
+        lens = [int(v) for v in rng.integers(0, T + 1, S)]
+        lens[0] = T
+        i, o = ins[k & 1], outs[k & 1]
+        blocks = []
+        for s in range(S):
+            x = _rand_pcm(rng, lens[s] * C, "full")
+            i.array[s, :x.size] = x
+            blocks.append(x)
+        b.run_slots(T, i.dev, o.dev, frames_per_stream=lens)
+        b.sync()
+        for s in range(S):
+            want = _oracle_block(oracle, blocks[s], C, (2, 1000, [750, 1250]), [1, 0] if s == 3 else None)
+            assert np.array_equal(o.array[s, :want.size], want), (k, s)
+            wants[s].append(want)
+    res, rcs = b.vu_results()
+    for s in range(S):
+        rc_o, ro = _oracle_vu(oracle, wants[s], C)
+        assert rcs[s] == rc_o and (rc_o != 0 or res[s].as_dict() == of.vu_result_dict(ro)), s
+    # no slots of its own
+    assert cm.lib.cmhip_batch_run(b.h, 10, None) == cm.ERROR_INVAL
+    x = np.zeros(10 * C, np.int16)
+    assert cm.lib.cmhip_batch_upload(b.h, 0, x.ctypes.data, 10) == cm.ERROR_INVAL
+    assert cm.lib.cmhip_batch_generate(b.h, 0, 0, 10, 0, 1, 0) == cm.ERROR_INVAL
+    assert cm.lib.cmhip_batch_run_slots(b.h, 10, None, ins[0].dev, None) == cm.ERROR_INVAL   # writes PCM: needs an output
+    for m in ins + outs:
+        m.free()
+    b.close()
