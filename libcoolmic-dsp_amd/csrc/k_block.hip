@@ -674,82 +674,8 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
         }
     };
 
-    // Steps of whole rows (every vector inside the stream's whole vectors -- everything but a stream's
-    // ragged end) without channel maps or float planes take a software-pipelined loop: the loads of the next
-    // step are in flight while this step is worked on, all of them unconditional (lanes beyond W
-    // repeat lane W-1's vector; what they compute is dropped at the merge) so that the compiler can
-    // count its waits.  Without it these runs are latency bound: a wave that loads, waits and then
-    // computes leaves the memory idle for as long as it computes.
-    // (a stream's last tile takes it for its whole steps and the ragged loop below for the rest)
-    u32 piped_rows = 0;
-    if (!MAP && !WRITE_F32) {
-        const u64 whole = (u64)nfull / W;                        // rows of whole vectors in the stream
-        const u64 here = whole > row0 ? whole - row0 : 0;
-        piped_rows = (u32)(here < rows_per_tile ? here : rows_per_tile) & ~(UR - 1u);
-    }
-    if (piped_rows) {
-        const u32 lw = active ? lane : W - 1u;
-        const u32x4 *srow = src + (u64)row0 * W + lw;
-        u32x4 *drow = dst + (u64)row0 * W + lw;
-        auto load4 = [&](u32 r0, u32 (&xx)[UR][4]) {
-#pragma unroll
-            for (u32 u = 0; u < UR; u++) {
-                const u32x4 w = __builtin_nontemporal_load(srow + (u64)(r0 + u) * W);
-                xx[u][0] = w.x; xx[u][1] = w.y; xx[u][2] = w.z; xx[u][3] = w.w;
-            }
-        };
-        auto work4 = [&](u32 r0, const u32 (&xx)[UR][4]) {
-            u32 o[UR][4];
-            arithmetic(r0 / UR, xx, o);
-            if constexpr (WRITE_PCM) {
-                if (active) {
-#pragma unroll
-                    for (u32 u = 0; u < UR; u++) {
-                        const u32x4 ov = {o[u][0], o[u][1], o[u][2], o[u][3]};
-                        __builtin_nontemporal_store(ov, drow + (u64)(r0 + u) * W);
-                    }
-                }
-            }
-        };
-        // (every pass of the loop issues its loads unconditionally -- the last step is peeled off)
-        u32 xa[UR][4], xb[UR][4];
-        load4(0, xa);
-        u32 r0 = 0;
-        for (; r0 + UR < piped_rows; r0 += UR) {
-            load4(r0 + UR, xb);
-            work4(r0, xa);
-#pragma unroll
-            for (u32 u = 0; u < UR; u++)
-#pragma unroll
-                for (u32 i = 0; i < 4; i++)
-                    xa[u][i] = xb[u][i];
-        }
-        work4(r0, xa);
-    }
-    for (u32 r0 = piped_rows; r0 < rows_per_tile; r0 += UR) {
-        if ((u64)(row0 + r0) * W >= nvec)
-            break;
-        u32 x[UR][4];
-        bool full[UR], tail[UR];
-#pragma unroll
-        for (u32 u = 0; u < UR; u++) {
-            const u32 v = (row0 + r0 + u) * W + lane;
-            full[u] = active && v < nfull;
-            tail[u] = active && ntail && v == nfull;
-            u32x4 w = {0, 0, 0, 0};
-            if (full[u])
-                w = __builtin_nontemporal_load(src + v);
-            x[u][0] = w.x; x[u][1] = w.y; x[u][2] = w.z; x[u][3] = w.w;
-            if (tail[u]) {
-                for (u32 j = 0; j < ntail; j++) {
-                    const u32 val = (u32)(uint16_t)ins[(u64)v * 8 + j];
-#pragma unroll
-                    for (u32 i = 0; i < 4; i++)
-                        if (i == (j >> 1))
-                            x[u][i] |= val << (16u * (j & 1u));
-                }
-            }
-        }
+    // everything after the loads of a step: channel map (through LDS), gain + VU, PCM and float stores
+    auto finish_step = [&](const u32 r0, u32 (&x)[UR][4], const bool (&full)[UR], const bool (&tail)[UR]) {
         if constexpr (MAP) {
             __syncthreads();                     // the previous rows have been gathered
 #pragma unroll
@@ -837,6 +763,76 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
             }
             __syncthreads();                              // before the next step overwrites the stage
         }
+    };
+    // Steps of whole rows (every vector inside the stream's whole vectors -- everything but a stream's
+    // ragged end) take a software-pipelined loop: the loads of the next step are in flight while this
+    // step is worked on, all of them unconditional (lanes beyond W repeat lane W-1's vector; what they
+    // compute is dropped at the merge and never stored) so that the compiler can count its waits.
+    // Without it these runs are latency bound: a wave that loads, waits and then computes leaves the
+    // memory idle for as long as it computes.
+    // (a stream's last tile takes it for its whole steps and the ragged loop below for the rest)
+    u32 piped_rows = 0;
+    {
+        const u64 whole = (u64)nfull / W;                        // rows of whole vectors in the stream
+        const u64 here = whole > row0 ? whole - row0 : 0;
+        piped_rows = (u32)(here < rows_per_tile ? here : rows_per_tile) & ~(UR - 1u);
+    }
+    if (piped_rows) {
+        const u32 lw = active ? lane : W - 1u;
+        const u32x4 *srow = src + (u64)row0 * W + lw;
+        auto load4 = [&](u32 r0, u32 (&xx)[UR][4]) {
+#pragma unroll
+            for (u32 u = 0; u < UR; u++) {
+                const u32x4 w = __builtin_nontemporal_load(srow + (u64)(r0 + u) * W);
+                xx[u][0] = w.x; xx[u][1] = w.y; xx[u][2] = w.z; xx[u][3] = w.w;
+            }
+        };
+        bool all_rows[UR], no_tail[UR];
+#pragma unroll
+        for (u32 u = 0; u < UR; u++) {
+            all_rows[u] = active;
+            no_tail[u] = false;
+        }
+        // (every pass of the loop issues its loads unconditionally -- the last step is peeled off)
+        u32 xa[UR][4], xb[UR][4];
+        load4(0, xa);
+        u32 r0 = 0;
+        for (; r0 + UR < piped_rows; r0 += UR) {
+            load4(r0 + UR, xb);
+            finish_step(r0, xa, all_rows, no_tail);
+#pragma unroll
+            for (u32 u = 0; u < UR; u++)
+#pragma unroll
+                for (u32 i = 0; i < 4; i++)
+                    xa[u][i] = xb[u][i];
+        }
+        finish_step(r0, xa, all_rows, no_tail);
+    }
+    for (u32 r0 = piped_rows; r0 < rows_per_tile; r0 += UR) {
+        if ((u64)(row0 + r0) * W >= nvec)
+            break;
+        u32 x[UR][4];
+        bool full[UR], tail[UR];
+#pragma unroll
+        for (u32 u = 0; u < UR; u++) {
+            const u32 v = (row0 + r0 + u) * W + lane;
+            full[u] = active && v < nfull;
+            tail[u] = active && ntail && v == nfull;
+            u32x4 w = {0, 0, 0, 0};
+            if (full[u])
+                w = __builtin_nontemporal_load(src + v);
+            x[u][0] = w.x; x[u][1] = w.y; x[u][2] = w.z; x[u][3] = w.w;
+            if (tail[u]) {
+                for (u32 j = 0; j < ntail; j++) {
+                    const u32 val = (u32)(uint16_t)ins[(u64)v * 8 + j];
+#pragma unroll
+                    for (u32 i = 0; i < 4; i++)
+                        if (i == (j >> 1))
+                            x[u][i] |= val << (16u * (j & 1u));
+                }
+            }
+        }
+        finish_step(r0, x, full, tail);
     }
     };
     if constexpr (MODES) {
