@@ -996,6 +996,12 @@ hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hip
             rpt = tune.rows_rpt;
         const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
         const u64 rows = (nvec + W - 1) / W;
+        if (ro && !tune.rows_rpt) {
+            // equal tiles: a stream of 98 rows is two tiles of 52, not one of 64 and a ragged one of 34
+            // whose merge costs as much as the whole tile's (3 and 6 channels at 16 384 frames: +8 %)
+            const u64 nt = (rows + rpt - 1) / rpt;
+            rpt = (u32)(((rows + nt - 1) / nt + 3u) & ~3ull);
+        }
         b.chunks = (u32)((rows + rpt - 1) / rpt);
         if (b.chunks == 0)
             b.chunks = 1;
