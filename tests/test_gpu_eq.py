@@ -324,3 +324,29 @@ def test_eq_non_finite_results_saturate_like_the_oracle(gpu, oracle):
         assert rc_g == rc_o == 0 and r_g.as_dict() == of.vu_result_dict(r_o), s
     assert saw_nan and saw_inf
     b.close()
+
+
+def test_eq_on_a_second_device_of_the_process(gpu, oracle):
+    """The EQ kernels need their dynamic-LDS limit raised per function AND per device (prepare_eq,
+    csrc/k_eq.hip): a host that drives several GPUs from one process creates EQ batches on each.
+    Needs two GPUs; the 1-GPU test box skips it."""
+    cm = gpu
+    if cm.device_count() < 2:
+        pytest.skip("one GPU visible")
+    S, T = 40, 700
+    coef = cm.eq3(48000.0)
+    rng = np.random.default_rng(12)
+    xs = [rng.integers(-32768, 32768, T).astype(np.int16) for _ in range(S)]
+    outs = []
+    for dev in (0, 1, 0):
+        b = cm.Batch(S, 1, T, flags=cm.EQ | cm.OUT_F32, device=dev)
+        assert b.set_eq(-1, coef) == 0
+        for s in range(S):
+            b.upload(s, xs[s])
+        b.run(T)
+        outs.append([b.download_f32(s, 0, T) for s in range(S)])
+        b.close()
+    for s in range(S):
+        (wf, _), = _oracle_eq(oracle, coef, 3, None, [xs[s]])
+        for k in range(3):
+            assert np.array_equal(outs[k][s].view(np.uint32), wf.view(np.uint32)), (k, s)
