@@ -362,13 +362,15 @@ void k_eq_pipe(EqArgs a)
                 } else if (__all(cnt == EP_TB)) {
 #pragma unroll
                     for (u32 t = 0; t < EP_TB / 4; t++) {
-                        float4 y;
-                        y.x = __builtin_fmaf(d1, h1, __builtin_fmaf(d2, h2, v[t].x));
-                        y.y = __builtin_fmaf(d1, y.x, __builtin_fmaf(d2, h1, v[t].y));
-                        y.z = __builtin_fmaf(d1, y.y, __builtin_fmaf(d2, y.x, v[t].z));
-                        y.w = __builtin_fmaf(d1, y.z, __builtin_fmaf(d2, y.y, v[t].w));
-                        h2 = y.z;
-                        h1 = y.w;
+                        float4 y = v[t];
+                        if (!(CMHIP_EQ_ABL & 256) || (t & 1u) == 0u) {      // (256: timing only, half the FMAs)
+                            y.x = __builtin_fmaf(d1, h1, __builtin_fmaf(d2, h2, v[t].x));
+                            y.y = __builtin_fmaf(d1, y.x, __builtin_fmaf(d2, h1, v[t].y));
+                            y.z = __builtin_fmaf(d1, y.y, __builtin_fmaf(d2, y.x, v[t].z));
+                            y.w = __builtin_fmaf(d1, y.z, __builtin_fmaf(d2, y.y, v[t].w));
+                            h2 = y.z;
+                            h1 = y.w;
+                        }
                         if (!(CMHIP_EQ_ABL & 8) || t == 0)
                             out[t] = y;
                     }
