@@ -125,6 +125,30 @@ struct PowAcc {
     }
 };
 
+// squares of the 16-bit halves of packed magnitudes, added into a u32 (three of them fit: 3 * 2^30)
+__device__ __forceinline__ u32 sq_lo0(u32 pair)
+{
+    u32 r;
+    asm("v_mad_u32_u16 %0, %1, %1, 0 op_sel:[0,0,0,0]" : "=v"(r) : "v"(pair));
+    return r;
+}
+__device__ __forceinline__ u32 sq_hi0(u32 pair)
+{
+    u32 r;
+    asm("v_mad_u32_u16 %0, %1, %1, 0 op_sel:[1,1,0,0]" : "=v"(r) : "v"(pair));
+    return r;
+}
+__device__ __forceinline__ u32 sq_lo(u32 pair, u32 acc)
+{
+    asm("v_mad_u32_u16 %0, %1, %1, %0 op_sel:[0,0,0,0]" : "+v"(acc) : "v"(pair));
+    return acc;
+}
+__device__ __forceinline__ u32 sq_hi(u32 pair, u32 acc)
+{
+    asm("v_mad_u32_u16 %0, %1, %1, %0 op_sel:[1,1,0,0]" : "+v"(acc) : "v"(pair));
+    return acc;
+}
+
 template <int C>
 __device__ __forceinline__ void store_f32(float *f32s, u64 plane, u32 v, const u32 (&o)[4])
 {

@@ -530,29 +530,6 @@ struct RowsVu {
     u32 sv[4][4];                                // [dword i][row of the step]: the results of the winning step
 };
 
-__device__ __forceinline__ u32 sq_lo0(u32 pair)
-{
-    u32 r;
-    asm("v_mad_u32_u16 %0, %1, %1, 0 op_sel:[0,0,0,0]" : "=v"(r) : "v"(pair));
-    return r;
-}
-__device__ __forceinline__ u32 sq_hi0(u32 pair)
-{
-    u32 r;
-    asm("v_mad_u32_u16 %0, %1, %1, 0 op_sel:[1,1,0,0]" : "=v"(r) : "v"(pair));
-    return r;
-}
-__device__ __forceinline__ u32 sq_lo(u32 pair, u32 acc)
-{
-    asm("v_mad_u32_u16 %0, %1, %1, %0 op_sel:[0,0,0,0]" : "+v"(acc) : "v"(pair));
-    return acc;
-}
-__device__ __forceinline__ u32 sq_hi(u32 pair, u32 acc)
-{
-    asm("v_mad_u32_u16 %0, %1, %1, %0 op_sel:[1,1,0,0]" : "+v"(acc) : "v"(pair));
-    return acc;
-}
-
 // one dword column (positions 2i, 2i+1) of one step: q = packed magnitudes, o = packed signed results
 __device__ __forceinline__ void rows_vu_column(RowsVu &v, const u32 i, const u32 (&q)[4], const u32 (&o)[4],
                                                const u32 steptag)

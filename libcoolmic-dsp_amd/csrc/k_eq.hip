@@ -546,12 +546,12 @@ void k_eq_pipe(EqArgs a)
         return 2u * (s_first + i) + (g4 >> 1) + ((g4 & 1u) ? 16u : 0u);
     };
     u64 vpw[NSL], vky[NSL], vbase[NSL];
-    u32 vmag[NSL], vidx[NSL];                             // running peak: magnitude, frame << 1 | negative
+    u32 vmag[NSL], vq01[NSL], vq23[NSL], vfr[NSL];        // running peak: magnitude, the four results it was among, their first frame
     u32 v_stream[NSL], v_ch[NSL];                         // stream (or none) and channel of the slot's row
 #pragma unroll
     for (u32 i = 0; i < NSL; i++) {
         vpw[i] = vky[i] = vbase[i] = 0;
-        vmag[i] = vidx[i] = 0;
+        vmag[i] = vq01[i] = vq23[i] = vfr[i] = 0;
         const u32 r = s_row(i);
         v_stream[i] = row_stream(r, v_ch[i]);
         if (v_stream[i] >= a.streams || i >= s_cnt)
@@ -561,6 +561,9 @@ void k_eq_pipe(EqArgs a)
     }
     auto s_step = [&](const u32 step) {
         eq_pad<CMHIP_EQ_PAD_S>();
+#ifdef CMHIP_EQ_S_SLEEP
+        __builtin_amdgcn_s_sleep(CMHIP_EQ_S_SLEEP);
+#endif
         if (!(CMHIP_EQ_ABL & 1)) {
             // --- the finished block of the last section leaves: 256 B (float) / 128 B (int16)
             // per stream row and instruction, fire and forget (this wave never waits for
@@ -606,28 +609,27 @@ void k_eq_pipe(EqArgs a)
                         for (u32 j = 0; j < 4; j++) {
                             const float r = __builtin_rintf(e[j] * 32768.0f);
                             asm("v_cvt_i32_f32 %0, %1" : "=v"(q[j]) : "v"(r));
-                            q[j] = q[j] > 32767 ? 32767 : (q[j] < -32768 ? -32768 : q[j]);
                         }
+                        // (v_cvt_pk_i16_i32 saturates: the clamp and the packing of a sample pair in one)
+                        const u32 p01 = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pk_i16(q[0], q[1]));
+                        const u32 p23 = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pk_i16(q[2], q[3]));
                         const bool whole = __all(f0 + 4u <= n);     // no stream ends inside these
                         if (a.out) {
                             if constexpr (MONO) {
                                 int16_t *d16 = a.out + (u64)vs_ * a.stride + f0;
                                 if (f0 + 4u <= n) {
                                     typedef u32 u32x2 __attribute__((ext_vector_type(2)));
-                                    const u32x2 pk = {((u32)q[0] & 0xffffu) | ((u32)q[1] << 16),
-                                                      ((u32)q[2] & 0xffffu) | ((u32)q[3] << 16)};
+                                    const u32x2 pk = {p01, p23};
                                     __builtin_nontemporal_store(pk, reinterpret_cast<u32x2 *>(d16));
                                 } else if (f0 < n) {
                                     for (u32 j = 0; j < n - f0; j++)
-                                        d16[j] = (int16_t)q[j];
+                                        d16[j] = (int16_t)((j < 2u ? p01 : p23) >> (16u * (j & 1u)));
                                 }
                             } else if constexpr (STEREO) {
                                 // The two rows of a stream are 32 lanes apart (s_row): swap halves with the
                                 // partner (v_permlane32_swap) so that the left row's lanes hold
                                 // frames f0, f0+1 of both channels and the right row's lanes frames
                                 // f0+2, f0+3 -- whole interleaved frames, 8 bytes per lane.
-                                const u32 p01 = ((u32)q[0] & 0xffffu) | ((u32)q[1] << 16);
-                                const u32 p23 = ((u32)q[2] & 0xffffu) | ((u32)q[3] << 16);
                                 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
                                 const u32x2 sw2 = __builtin_amdgcn_permlane32_swap(p01, p23, false, false);
                                 const u32 left = sw2.x, right = sw2.y;   // this frame pair: channel 0, channel 1
@@ -646,23 +648,33 @@ void k_eq_pipe(EqArgs a)
 #pragma unroll
                                 for (u32 j = 0; j < 4; j++)
                                     if (f0 + j < n)
-                                        d16[j * C] = (int16_t)q[j];
+                                        d16[j * C] = (int16_t)((j < 2u ? p01 : p23) >> (16u * (j & 1u)));
                             }
                         }
                         if (a.vu) {
-                            // running peak of the lane's samples of this row: they come in time order,
-                            // so "strictly greater" keeps the first of equals; the 64-bit key is built
-                            // once, after the loop
-#pragma unroll
-                            for (u32 j = 0; j < 4; j++) {
-                                u32 am = (u32)(q[j] < 0 ? -q[j] : q[j]);
-                                if (!whole)
-                                    am = f0 + j < n ? am : 0u;
-                                vpw[i] += (u64)am * am;
-                                const bool gt = am > vmag[i];
-                                vmag[i] = gt ? am : vmag[i];
-                                vidx[i] = gt ? ((f0 + j) << 1) | ((u32)q[j] >> 31) : vidx[i];
+                            // The window of the int16 result on packed pairs (as the block kernels do): the
+                            // magnitudes of four samples in six instructions, their squares in one chain of
+                            // three v_mad_u32_u16 and a fourth, and one comparison of the four's maximum
+                            // with the lane's running peak -- a lane whose peak improves keeps the four
+                            // results and their first frame; which of them came first, and its sign, is
+                            // looked up once, after the loop.  (The samples come in time order, so "strictly
+                            // greater" keeps the first of equals.)
+                            u32 v01 = p01, v23 = p23;     // the results that count: all four, unless a stream ends here
+                            if (!whole) {                 // (uniform branch; what lies beyond a stream's end counts nothing)
+                                v01 &= (f0 + 0u < n ? 0xffffu : 0u) | (f0 + 1u < n ? 0xffff0000u : 0u);
+                                v23 &= (f0 + 2u < n ? 0xffffu : 0u) | (f0 + 3u < n ? 0xffff0000u : 0u);
                             }
+                            const u32 s01 = pk_sign(v01), s23 = pk_sign(v23);
+                            const u32 m01 = pk_sub(v01 ^ s01, s01), m23 = pk_sub(v23 ^ s23, s23);
+                            vpw[i] += sq_lo(m23, sq_hi(m01, sq_lo0(m01)));
+                            vpw[i] += sq_hi0(m23);
+                            const u32 mm = pk_max(m01, m23);
+                            const u32 m4 = max(mm & 0xffffu, mm >> 16);
+                            const bool gt = m4 > vmag[i];
+                            vmag[i] = gt ? m4 : vmag[i];
+                            vq01[i] = gt ? v01 : vq01[i];
+                            vq23[i] = gt ? v23 : vq23[i];
+                            vfr[i] = gt ? f0 : vfr[i];
                         }
                     }
                 }
@@ -710,7 +722,19 @@ void k_eq_pipe(EqArgs a)
         // the 16 lanes of a row hold parts of its window; lane 0 of them is the row's only writer
 #pragma unroll
         for (u32 i = 0; i < NSL; i++) {
-            vky[i] = make_key(vmag[i], vbase[i] + (u64)(vidx[i] >> 1) * C + v_ch[i], vidx[i] & 1u);
+            {
+                u32 first = 0, neg = 0;                   // the first of the four with that magnitude, and its sign
+#pragma unroll
+                for (u32 j = 4; j-- > 0;) {
+                    const int sv = (int)(short)(((j < 2u ? vq01[i] : vq23[i]) >> (16u * (j & 1u))) & 0xffffu);
+                    const u32 am = (u32)(sv < 0 ? -sv : sv);
+                    if (am == vmag[i]) {
+                        first = j;
+                        neg = sv < 0 ? 1u : 0u;
+                    }
+                }
+                vky[i] = make_key(vmag[i], vbase[i] + (u64)(vfr[i] + first) * C + v_ch[i], neg);
+            }
             u64 pw = vpw[i], ky = vky[i];
 #pragma unroll
             for (int o = SPR / 2; o > 0; o >>= 1) {

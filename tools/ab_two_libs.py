@@ -2,7 +2,7 @@
 """A/B of several builds of the library in ONE process, interleaved, at sustained clocks: every library
 is loaded under a module name of its own, each gets its own batch of the same shape, and timed
 blocks of launches alternate between them (process-to-process differences -- placement of the
-arrays, clocks -- cancel).  usage: ab_two_libs.py SHAPE lib1.so lib2.so ...   SHAPE: eq3 | eq3vu | c2 | vu6"""
+arrays, clocks -- cancel).  usage: ab_two_libs.py SHAPE lib1.so lib2.so ...   SHAPE: eq3 | eq3vu | eq3vu1 | eq3all | eq3vu6 | c2 | vu6"""
 import importlib.util
 import os
 import sys
@@ -24,13 +24,13 @@ def load(lib_path, tag):
 
 def make(cm, shape):
     T = 65536
-    if shape in ("eq3", "eq3vu"):
-        S, C = (8192, 1) if shape == "eq3" else (4096, 2)
-        flags = cm.EQ | (cm.OUT_F32 if shape == "eq3" else cm.OUT_PCM | cm.VU)
+    if shape in ("eq3", "eq3vu", "eq3vu1", "eq3all", "eq3vu6"):
+        S, C = {"eq3": (8192, 1), "eq3vu": (4096, 2), "eq3vu1": (8192, 1), "eq3all": (4096, 2), "eq3vu6": (1365, 6)}[shape]
+        flags = cm.EQ | {"eq3": cm.OUT_F32, "eq3all": cm.OUT_F32 | cm.OUT_PCM | cm.VU}.get(shape, cm.OUT_PCM | cm.VU)
         b = cm.Batch(S, C, T, flags=flags)
         b.set_eq(-1, cm.eq3())
         b.set_gain(-1, 1, 1000, [900])
-        bps = 6 if shape == "eq3" else 4
+        bps = {"eq3": 6, "eq3all": 8}.get(shape, 4)
     elif shape == "c2":
         S, C, bps = 4096, 2, 4
         b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU)
