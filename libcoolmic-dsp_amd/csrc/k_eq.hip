@@ -308,6 +308,24 @@ void k_eq_pipe(EqArgs a)
         }
         return r;
     };
+    // Section 0's x1 / x2 for the next launch are the last two samples of the row after the gain.
+    // On mono rows one lane per row fetches them here, before the loop, straight from the input (still intact also
+    // when the result is written in place: the first store is many barriers away), instead of every
+    // T lane watching for the end of its stream in every step.
+    float keep1 = 0.f, keep2 = 0.f;
+    u32 keep_n = 0;                                       // bit 0: keep1 is to be written, bit 1: keep2
+    if (MONO && l_live && l_c == 0u && l_n >= 1u) {
+        keep_n = 3u;
+        auto gain_one = [&](const u32 frame) -> float {
+            const int xs = (int)l_src[MONO ? frame : frame * C + l_m];
+            const u32 ax = (u32)(xs < 0 ? -xs : xs);
+            const u32 qq = __umulhi(__umul24(ax, l_g2), l_magic) >> l_shift;
+            const float m = fminf((float)qq, xs < 0 ? 32768.0f : 32767.0f);
+            return (xs < 0 ? -m : m) * (1.0f / 32768.0f);
+        };
+        keep1 = gain_one(l_n - 1u);
+        keep2 = l_n >= 2u ? gain_one(l_n - 2u) : a.state[l_sidx].s[0][0];
+    }
     Pcm wa = {{0, 0, 0, 0}, {0, 0, 0, 0}}, wb = wa;       // blocks of even / odd steps
     if (is_tin) {
         wa = fetch(0);
@@ -395,8 +413,6 @@ void k_eq_pipe(EqArgs a)
             }
         }
     };
-    float keep1 = 0.f, keep2 = 0.f;                       // section 0's new x1 / x2, if seen
-    bool has1 = false, has2 = false;
     auto tin_step = [&](Pcm &wcur, const u32 step) {
         eq_pad<CMHIP_EQ_PAD_TIN>();
         if (!(CMHIP_EQ_ABL & 128)) {
@@ -450,33 +466,36 @@ void k_eq_pipe(EqArgs a)
                         x[2 * q + 1] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, b1), -32768.0f, 32767.0f);
                     }
                 }
-                // The last real samples of a stream are section 0's x1/x2 for the next launch
-                // (unscaled form here, see above); they pass through exactly one lane each and
-                // are written after the loop.
-                const u32 bf = b * EP_TB;
-                if (l_live && l_n > bf && l_n <= bf + EP_TB) {
-                    const u32 e1 = l_n - 1u - bf;                     // last sample, block relative
-                    if ((e1 >> 3) == l_c) {
-                        float val = x[0];
-#pragma unroll
-                        for (u32 j = 1; j < 8; j++)
-                            val = (e1 & 7u) == j ? x[j] : val;
-                        keep1 = val;
-                        has1 = true;
-                    }
-                    if (e1 >= 1u) {
-                        const u32 e2 = e1 - 1u;
-                        if ((e2 >> 3) == l_c) {
+                // (Stereo and many-channel rows watch for the end of their stream inside the loop, as in round
+                // 1: the last real samples pass through exactly one lane each.  The mono form fetches them
+                // before the loop -- the same loop without this block ran 1.7 % faster on mono rows and
+                // 4.7 % slower on stereo ones, A/B in one process.)
+                if constexpr (!MONO) {
+                    const u32 bf = b * EP_TB;
+                    if (l_live && l_n > bf && l_n <= bf + EP_TB) {
+                        const u32 e1 = l_n - 1u - bf;                     // last sample, block relative
+                        if ((e1 >> 3) == l_c) {
                             float val = x[0];
 #pragma unroll
                             for (u32 j = 1; j < 8; j++)
-                                val = (e2 & 7u) == j ? x[j] : val;
-                            keep2 = val;
-                            has2 = true;
+                                val = (e1 & 7u) == j ? x[j] : val;
+                            keep1 = val * (1.0f / 32768.0f);
+                            keep_n |= 1u;
                         }
-                    } else if (l_c == 7u) {
-                        keep2 = sx1[0][0];                            // the sample before this block
-                        has2 = true;
+                        if (e1 >= 1u) {
+                            const u32 e2 = e1 - 1u;
+                            if ((e2 >> 3) == l_c) {
+                                float val = x[0];
+#pragma unroll
+                                for (u32 j = 1; j < 8; j++)
+                                    val = (e2 & 7u) == j ? x[j] : val;
+                                keep2 = val * (1.0f / 32768.0f);
+                                keep_n |= 2u;
+                            }
+                        } else if (l_c == 7u) {
+                            keep2 = sx1[0][0] * (1.0f / 32768.0f);        // the sample before this block
+                            keep_n |= 2u;
+                        }
                     }
                 }
 #ifdef CMHIP_EQ_STAMPS
@@ -710,10 +729,10 @@ void k_eq_pipe(EqArgs a)
             EQ_STEP(tin_step(wa, step));
             EQ_STEP(tin_step(wb, step + 1));
         }
-        if (has1)
-            a.state[l_sidx].s[0][0] = keep1 * (1.0f / 32768.0f);
-        if (has2)
-            a.state[l_sidx].s[0][1] = keep2 * (1.0f / 32768.0f);
+        if (keep_n & 1u)
+            a.state[l_sidx].s[0][0] = keep1;
+        if (keep_n & 2u)
+            a.state[l_sidx].s[0][1] = keep2;
     }
 #undef EQ_STEP
 
