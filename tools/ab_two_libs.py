@@ -24,13 +24,13 @@ def load(lib_path, tag):
 
 def make(cm, shape):
     T = 65536
-    if shape in ("eq3", "eq3vu", "eq3vu1", "eq3all", "eq3vu6"):
-        S, C = {"eq3": (8192, 1), "eq3vu": (4096, 2), "eq3vu1": (8192, 1), "eq3all": (4096, 2), "eq3vu6": (1365, 6)}[shape]
-        flags = cm.EQ | {"eq3": cm.OUT_F32, "eq3all": cm.OUT_F32 | cm.OUT_PCM | cm.VU}.get(shape, cm.OUT_PCM | cm.VU)
+    if shape in ("eq3", "eq3vu", "eq3vu1", "eq3all", "eq3vu6", "eq3f2"):
+        S, C = {"eq3": (8192, 1), "eq3vu": (4096, 2), "eq3vu1": (8192, 1), "eq3all": (4096, 2), "eq3vu6": (1365, 6), "eq3f2": (4096, 2)}[shape]
+        flags = cm.EQ | {"eq3": cm.OUT_F32, "eq3f2": cm.OUT_F32, "eq3all": cm.OUT_F32 | cm.OUT_PCM | cm.VU}.get(shape, cm.OUT_PCM | cm.VU)
         b = cm.Batch(S, C, T, flags=flags)
         b.set_eq(-1, cm.eq3())
         b.set_gain(-1, 1, 1000, [900])
-        bps = {"eq3": 6, "eq3all": 8}.get(shape, 4)
+        bps = {"eq3": 6, "eq3f2": 6, "eq3all": 8}.get(shape, 4)
     elif shape == "c2":
         S, C, bps = 4096, 2, 4
         b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU)
