@@ -156,3 +156,57 @@ def test_witness_reproduces_the_hand_checkable_vectors(golden):
         _, r = v.result()
         for key, want in case["vu"].items():
             assert r[key] == want, (name, key)
+
+
+# ---- the VU colour helpers, written from ref: src/util.c:30-138 ---------------------
+
+def _x255(x):
+    x = 1.0 if x >= 1.0 else (0.0 if x <= 0.0 else x)
+    return min(int(x * 255.0), 255)
+
+
+def witness_ahsv2argb(alpha, hue, sat, value):
+    hue1 = int(hue / (math.pi / 3.0))                     # C's (int): truncation toward zero
+    f = hue - float(hue1)
+    p_ = value * (1.0 - sat)
+    q_ = value * (1.0 - sat * f)
+    t_ = value * (1.0 - sat * (1.0 - f))
+    rgb = {0: (value, t_, p_), 6: (value, t_, p_), 1: (q_, value, p_), 2: (p_, value, t_),
+           3: (p_, q_, value), 4: (t_, p_, value), 5: (value, p_, q_)}.get(hue1, (0.0, 0.0, 0.0))
+    return (_x255(alpha) << 24) + (_x255(rgb[0]) << 16) + (_x255(rgb[1]) << 8) + _x255(rgb[2])
+
+
+def witness_power2hue(power):
+    if power < -20.0:
+        return math.pi * 2.0 / 3.0
+    if power >= 0:
+        return 0.0
+    return math.pow(math.sin(math.pi * power / 40.0), 2.0) * math.pi * 2.0 / 3.0
+
+
+def witness_peak2hue(peak):
+    if peak in (-32768, 32767):
+        return 0.0
+    if peak < -30000 or peak > 30000:
+        return 0.43
+    if peak < -28000 or peak > 28000:
+        return 1.0
+    return math.pi * 2.0 / 3.0
+
+
+def test_colour_helpers_against_the_python_witness(oracle, cm):
+    """product (csrc/util.c) and oracle restatement against a third, independent one"""
+    rng = np.random.default_rng(99)
+    for _ in range(400):
+        a, h, sat, v = rng.uniform(-0.2, 1.3), rng.uniform(0.0, 2.0 * math.pi + 0.2), rng.uniform(0, 1), rng.uniform(-0.1, 1.4)
+        want = witness_ahsv2argb(a, h, sat, v)
+        assert oracle.lib.oracle_ahsv2argb(a, h, sat, v) == want
+        assert cm.lib.coolmic_util_ahsv2argb(a, h, sat, v) == want
+    for p in list(rng.uniform(-60.0, 3.0, 200)) + [-20.0, -20.000001, 0.0, -1e-12, -math.inf]:
+        want = witness_power2hue(float(p))
+        assert oracle.lib.oracle_power2hue(float(p)) == want
+        assert cm.lib.coolmic_util_power2hue(float(p), b"default") == want
+    for pk in list(rng.integers(-32768, 32768, 300)) + [-32768, 32767, -30001, -30000, 30000, 30001, -28001, 28001, 28000]:
+        want = witness_peak2hue(int(pk))
+        assert oracle.lib.oracle_peak2hue(int(pk)) == want
+        assert cm.lib.coolmic_util_peak2hue(int(pk), b"default") == want
