@@ -93,10 +93,16 @@ def launch_ranks(n):
         env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    line = b""
-    for raw in procs[0].stdout:                 # rank 0 prints exactly one line on stdout
-        if raw.strip():
-            line = raw
+    lines = []
+
+    def drain():                                # rank 0 prints exactly one line on stdout
+        for raw in procs[0].stdout:
+            if raw.strip():
+                lines.append(raw)
+
+    import threading
+    reader = threading.Thread(target=drain, daemon=True)
+    reader.start()
     worst = 0
     deadline = None
     pending = list(procs)
@@ -115,6 +121,8 @@ def launch_ranks(n):
                 p.kill()                        # exactly the processes started above
             deadline = time.time() + 1e9
         time.sleep(0.05)
+    reader.join(timeout=10)
+    line = lines[-1] if lines else b""
     if line:
         sys.stdout.write(line.decode())
         sys.stdout.flush()
@@ -544,6 +552,8 @@ def main():
 
 
 def dry_run(args, rank, world, json_fd, shard):
+    if os.environ.get("COOLMIC_BENCH_DRYRUN_FAIL_RANK") == str(rank):      # (test hook: a rank that dies early)
+        sys.exit(3)
     uid = exchange_node_id(rank, world, lambda: os.urandom(128)) if args.workload == "c5" else b""
     out = {"metric": "Msamples/s transform->vumeter", "value": 0.0, "unit": "Msamples/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "dry_run": True,

@@ -54,3 +54,15 @@ def test_a_failing_rank_fails_the_launch():
     assert p.returncode != 0
     assert p.stdout.decode().strip() == ""
     assert b"no HIP device" in p.stderr
+
+
+def test_a_rank_that_dies_does_not_leave_the_others_at_the_rendezvous():
+    """rank 1 exits before the rendezvous; rank 0 would wait for it for half an hour: the parent gives
+    the survivors 20 s, ends them, reports the failure and prints no line"""
+    import time
+    t0 = time.time()
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1"],
+             {"COOLMIC_BENCH_DRYRUN": "1", "COOLMIC_BENCH_DRYRUN_FAIL_RANK": "1"}, timeout=120)
+    assert p.returncode == 3
+    assert p.stdout.decode().strip() == ""
+    assert time.time() - t0 < 90
