@@ -140,6 +140,7 @@ struct cmhip_batch {
     bool timing;
     std::vector<EventPair> ev_used, ev_free;
     RunTune tune;                          // launcher knobs, read once at creation
+    bool vu_off;                           // runs leave the windows alone for now (cmhip_batch_vu_pause)
 };
 
 static RunTune read_tune()
@@ -451,6 +452,7 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->nsec = 0;
     b->timing = false;
     b->tune = read_tune();
+    b->vu_off = false;
     if (batch_init(b) != COOLMIC_ERROR_NONE) {
         cmhip_batch_free(b);
         return nullptr;
@@ -955,7 +957,7 @@ static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per
     if (flush_params(b) || settle_node(b))
         return COOLMIC_ERROR_GENERIC;
 
-    const bool vu = (b->d.flags & CMHIP_VU) != 0;
+    const bool vu = (b->d.flags & CMHIP_VU) != 0 && !b->vu_off;
     EventPair ev{};                          // timing: the events take the kernel's own start and end
     if (b->timing) {
         ev = take_events(b);
@@ -1278,6 +1280,14 @@ int cmhip_batch_node_partial_side(cmhip_batch_t *b, long long *dst_sum, long lon
 }
 
 void *cmhip_batch_side_stream(cmhip_batch_t *b) { return (void *)b->copy_stream; }
+
+// internal (transform.c): a batch with windows runs without touching them while paused -- the
+// transform accumulates only the blocks its fused meter has asked for
+extern "C" __attribute__((visibility("hidden"))) void cmhip_batch_vu_pause(cmhip_batch_t *b, int paused)
+{
+    if (b)
+        b->vu_off = paused != 0;
+}
 
 int cmhip_batch_device(const cmhip_batch_t *b) { return b->d.device; }
 unsigned int cmhip_batch_flags(const cmhip_batch_t *b) { return b->d.flags; }

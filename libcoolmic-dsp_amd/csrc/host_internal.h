@@ -29,6 +29,11 @@ int coolmic_hip_default_device(void);
 struct coolmic_transform;
 struct coolmic_transform *coolmic_iohandle_as_transform(coolmic_iohandle_t *h);
 int coolmic_transform_fuse_vu(struct coolmic_transform *self, int on);
+/* the meter brackets its own reads with arm(1) / arm(0): only their frames enter the window, whoever
+ * else reads the transform's handle meanwhile */
+void coolmic_transform_arm_vu(struct coolmic_transform *self, int armed);
+struct cmhip_batch;
+void cmhip_batch_vu_pause(struct cmhip_batch *b, int paused);
 int coolmic_transform_vu_result(struct coolmic_transform *self, coolmic_vumeter_result_t *result);
 int coolmic_transform_vu_reset(struct coolmic_transform *self);
 void coolmic_transform_format(const struct coolmic_transform *self, uint_least32_t *rate, unsigned int *channels);

@@ -47,6 +47,7 @@ struct coolmic_transform {
     int fused_vu;                      /* a VU meter sits directly on this transform's handle: the launch
                                         * that transforms a block also accumulates its window (one launch
                                         * per pull instead of two; coolmic_transform_fuse_vu) */
+    int vu_armed;                      /* ... for the read that is under way: it is the meter's own */
 };
 
 static void transform_destroy(void *self)
@@ -127,7 +128,7 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
     /* nothing to do, exactly as the reference (ref: src/transform.c:107-108) -- but a device
      * that exists must still hear about it: "equaliser off" also clears the filter state, and
      * a later set_eq() must not filter on from what the old one left behind */
-    idle = scale == 0 && identity && eq_sections == 0 && !t->fused_vu;
+    idle = scale == 0 && identity && eq_sections == 0 && !(t->fused_vu && t->vu_armed);
     if (idle && t->dev == NULL) {
         if (dirty || eq_clear)         /* a batch made later starts from zero state and uploads everything */
             transform_settled(t, gen);
@@ -173,6 +174,7 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
     }
     if (idle)
         return 0;
+    cmhip_batch_vu_pause(t->dev, !(t->fused_vu && t->vu_armed));
     while (frames) {
         const size_t n = frames < TRANSFORM_SLICE_FRAMES ? frames : TRANSFORM_SLICE_FRAMES;
         if (cmhip_batch_upload(t->dev, 0, pcm, n) != COOLMIC_ERROR_NONE ||
@@ -251,9 +253,16 @@ int coolmic_transform_fuse_vu(coolmic_transform_t *self, int on)
     if (on && self->fused_vu)
         return COOLMIC_ERROR_BUSY;
     self->fused_vu = on ? 1 : 0;
+    self->vu_armed = 0;
     if (self->dev != NULL && cmhip_batch_vu_reset(self->dev, 0) != COOLMIC_ERROR_NONE)
         return COOLMIC_ERROR_GENERIC;
     return COOLMIC_ERROR_NONE;
+}
+
+void coolmic_transform_arm_vu(coolmic_transform_t *self, int armed)
+{
+    if (self != NULL)
+        self->vu_armed = armed ? 1 : 0;
 }
 
 int coolmic_transform_vu_result(coolmic_transform_t *self, coolmic_vumeter_result_t *result)

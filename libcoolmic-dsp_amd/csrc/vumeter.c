@@ -148,7 +148,11 @@ ssize_t coolmic_vumeter_read(coolmic_vumeter_t *self, ssize_t maxlen)
     want = sizeof(self->buffer) - self->fill;
     if (maxlen >= 0 && want > (size_t)maxlen)
         want = (size_t)maxlen;
+    if (self->fused != NULL)
+        coolmic_transform_arm_vu(self->fused, 1);      /* the frames of this read are ours */
     got = coolmic_iohandle_read(self->in, self->buffer + self->fill, want);
+    if (self->fused != NULL)
+        coolmic_transform_arm_vu(self->fused, 0);
     coolmic_logging_log(COOLMIC_LOGGING_LEVEL_DEBUG, COOLMIC_ERROR_NONE,
                         "Physical read on iohandle returned %zi bytes", got);
     if (got < 0) {

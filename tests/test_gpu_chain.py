@@ -296,6 +296,12 @@ def test_meter_directly_on_a_transform_shares_its_launch(gpu, oracle):
                                 ((1, 3, [2]), [100, -1], 6)):
         assert tr.set_master_gain(*(gain if gain else (0, 0, None))) == 0
         v = window(nreads, sizes, gain)
+        # someone else reads the transform's handle in between: transformed PCM for them, and none of
+        # it in the meter's window (the meter arms the window only around its own reads)
+        n, data = h.read(120)
+        rcg, g = oracle.gain(C, *gain) if gain else (0, of.Gain())
+        assert n == 120 and np.array_equal(np.frombuffer(data, np.int16), oracle.gain_apply(g, x[pos // 2: pos // 2 + 60], C))
+        pos += n
         rc, r = vu.result()
         rc_o, r_o = oracle.vu_result(v)
         assert rc == rc_o == 0 and r.as_dict() == of.vu_result_dict(r_o), gain
