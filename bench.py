@@ -20,6 +20,7 @@ no data-path collective, "weak" scaling):
   c4  8192 mono streams x 65536 frames, gain 900/1000, PCM materialised  [configs[3]]
   c5  c4 + node-global VU: RCCL all-reduce of the blocks' records         [configs[4]]
   c3  8192 mono streams, int16 -> float + 3-band EQ, float out           [configs[2]]
+  x6  2730 six-channel streams x 16384 frames, PCM + VU (the many-channel kernel; for profiles/)
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, timed with HIP
 events on the stream it is launched on; `cpu_baseline` is the CPU oracle (the scalar
@@ -49,6 +50,9 @@ WORKLOADS = {
     "c5": (8192, 1, 65536, 4, "c4 + node-global VU via RCCL all-reduce of the blocks' records"),
     "c3": (8192, 1, 65536, 6, "8192 mono streams x 65536 frames per GPU, int16 -> float + "
                               "3-band biquad EQ, planar float out"),
+    # not a BASELINE config: the many-channel kernel (k_run_rows) under the same harness, for profiles/
+    "x6": (2730, 6, 16384, 4, "2730 six-channel (5.1) streams x 16384 frames per GPU, gain 900/1000 -> VU, "
+                              "PCM materialised"),
 }
 
 
@@ -379,7 +383,7 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-        "kernel": "k_eq_pipe" if eq else "k_run_fast", "kernel_avg_ms": round(kern_avg_ms, 4),
+        "kernel": "k_eq_pipe" if eq else ("k_run_rows" if Cn > 2 else "k_run_fast"), "kernel_avg_ms": round(kern_avg_ms, 4),
         "launches": launches, "algorithmic_bytes_per_sample": bps,
         "algorithmic_bytes_per_launch": samples_per_step_rank * bps,
     }

@@ -5,10 +5,12 @@ set -e
 cp gpurun_out/bench_default.json profiles/${R}_bench_default.json
 cp gpurun_out/c2_rocprof.json profiles/${R}_c2_bench_under_rocprof.json
 cp gpurun_out/c3_rocprof.json profiles/${R}_c3_bench_under_rocprof.json
+cp gpurun_out/x6_rocprof.json profiles/${R}_x6_bench_under_rocprof.json
 # (gpurun merges into gpurun_out/, so older runs' files may still be there: take the newest)
 cp "$(ls -t gpurun_out/prof_c2/*/*_kernel_stats.csv | head -1)" profiles/${R}_c2_kernel_stats.csv
 cp "$(ls -t gpurun_out/prof_c3/*/*_kernel_stats.csv | head -1)" profiles/${R}_c3_kernel_stats.csv
-for w in c2 c3; do
+cp "$(ls -t gpurun_out/prof_x6/*/*_kernel_stats.csv | head -1)" profiles/${R}_x6_kernel_stats.csv
+for w in c2 c3 x6; do
     cp gpurun_out/pmc_$w.json profiles/${R}_${w}_pmc.json
     cp gpurun_out/pmc_$w.json profiles/pmc_$w.json
 done

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end checks on the GPU box: GPU tests, smoke, the default bench line, rocprofv3 kernel stats of
-# configs 3 and 2, HBM counters of both (tools/hbm_pmc.sh).  Everything lands under gpurun_out/.
+# configs 3 and 2 and of the six-channel workload x6, HBM counters of the three (tools/hbm_pmc.sh).  Everything lands under gpurun_out/.
 set -e
 R=$PWD
 mkdir -p gpurun_out
@@ -15,9 +15,13 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 cat $R/gpurun_out/c3_rocprof.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2 -- python3 $R/bench.py --steps 100 --warmup 100 --no-cpu --no-extras > $R/gpurun_out/c2_rocprof.json 2> $R/gpurun_out/c2_rocprof.err
 cat $R/gpurun_out/c2_rocprof.json
+rm -rf $R/gpurun_out/prof_x6
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_x6 -- python3 $R/bench.py --workload x6 --steps 100 --warmup 100 --no-cpu --no-extras > $R/gpurun_out/x6_rocprof.json 2> $R/gpurun_out/x6_rocprof.err
+cat $R/gpurun_out/x6_rocprof.json
 cd $R
 timeout -k 10 300 bash tools/hbm_pmc.sh c2 > gpurun_out/hbm_c2.log 2>&1 && tail -8 gpurun_out/hbm_c2.log
 timeout -k 10 300 bash tools/hbm_pmc.sh c3 > gpurun_out/hbm_c3.log 2>&1 && tail -8 gpurun_out/hbm_c3.log
+timeout -k 10 300 bash tools/hbm_pmc.sh x6 > gpurun_out/hbm_x6.log 2>&1 && tail -8 gpurun_out/hbm_x6.log
 # the N = 1 lines of the other workloads (config 5 with a one-rank RCCL communicator: all a 1-GPU box holds),
 # the 2-rank rehearsal of the self-launching bench on one GPU, and the tables DESIGN.md quotes
 timeout -k 10 300 python bench.py --workload c4 --no-extras --no-cpu > gpurun_out/n1_c4.json 2> gpurun_out/n1_c4.err
