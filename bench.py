@@ -346,7 +346,11 @@ def main():
     device_sync()
     warm_ms = (time.perf_counter() - t_w) * 1e3
 
-    b.timing(True)
+    # Kernel time: the kernel's own dispatch stamps HIP events on its stream.  The events cost a launch about
+    # 5 us of its stream's time (tools/step_overhead.py: 0.3334 -> 0.3380 ms per step of config 2), so every
+    # eighth launch of the timed region carries them, every one when the region is short.
+    time_every = 8 if args.steps >= 64 else 1
+    b.timing(time_every)
     b.timing_read()
     barrier()
     t0 = time.perf_counter()
@@ -384,7 +388,9 @@ def main():
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
         "kernel": "k_eq_pipe" if eq else ("k_run_rows" if Cn > 2 else "k_run_fast"), "kernel_avg_ms": round(kern_avg_ms, 4),
-        "launches": launches, "algorithmic_bytes_per_sample": bps,
+        "launches": launches, "launches_timed": "every %d%s of the %d timed steps" % (
+            time_every, "th" if time_every > 1 else "", args.steps) if time_every > 1 else "all",
+        "algorithmic_bytes_per_sample": bps,
         "algorithmic_bytes_per_launch": samples_per_step_rank * bps,
     }
 

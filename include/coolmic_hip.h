@@ -204,7 +204,9 @@ int cmhip_node_fetch(cmhip_node_t *n, unsigned int set, unsigned int count, int6
 int cmhip_node_merge_host(const int64_t *records, unsigned int nranks, int64_t *out);
 
 /* ---- measurement ----------------------------------------------------------- */
-/* when enabled every run is bracketed by hipEvents on the batch's stream */
+/* enable = 1: every run is bracketed by hipEvents on the batch's stream (stamped by the kernel's own
+ * dispatch); enable = n > 1: every n-th run only -- the events cost a run about 5 us of its stream's time,
+ * a sample of the launches leaves the throughput as it is without them; 0: off */
 int cmhip_batch_timing(cmhip_batch_t *b, int enable);
 /* sums since the last call: milliseconds and launches of the dominant kernel; resets */
 int cmhip_batch_timing_read(cmhip_batch_t *b, double *kernel_ms, unsigned int *launches);

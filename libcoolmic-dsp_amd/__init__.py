@@ -375,7 +375,8 @@ class Batch:
 
     # measurement
     def timing(self, enable):
-        _check("timing", lib.cmhip_batch_timing(self.h, 1 if enable else 0))
+        """True / 1: every run carries events; n > 1: every n-th run; False / 0: off"""
+        _check("timing", lib.cmhip_batch_timing(self.h, int(enable)))
 
     def timing_read(self):
         ms, n = C.c_double(), C.c_uint()

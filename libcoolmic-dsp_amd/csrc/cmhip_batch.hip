@@ -138,6 +138,7 @@ struct cmhip_batch {
     unsigned int parity;                   // current slot of VuState::samples
 
     bool timing;
+    unsigned int timing_every, timing_count;     // every n-th run carries the events (cmhip_batch_timing)
     std::vector<EventPair> ev_used, ev_free;
     RunTune tune;                          // launcher knobs, read once at creation
     bool vu_off;                           // runs leave the windows alone for now (cmhip_batch_vu_pause)
@@ -158,6 +159,15 @@ static RunTune read_tune()
         if (v == 8 || v == 16 || v == 32 || v == 64)      // the tile sizes the kernels are tested with
             t.rows_rpt = (uint32_t)v;
     }
+    if (const char *e = getenv("CMHIP_FAST_NW")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 4 || v == 8)
+            t.fast_nw = (uint32_t)v;
+    }
+    if (const char *e = getenv("CMHIP_PLACE"))
+        t.place_off = atoi(e) == 0 ? 1u : 0u;
+    if (getenv("CMHIP_PLACE_DEBUG"))
+        t.place_debug = 1;
     return t;
 }
 
@@ -285,6 +295,88 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     delete b;
 }
 
+// Placement of the PCM output array.  On MI355X a kernel that streams one large array in and another
+// out runs 3-5 % faster when the two lie in different stretches of the card's memory (measured:
+// tools/placement_probe*.py, DESIGN 4.1 -- physical memory falls into stretches of up to 32 GiB of
+// three kinds; reads and writes that go to the same kind get in each other's way, and of the pairs
+// of different kinds some are better than others).  Nothing but the virtual address is visible from
+// here, so the output array is chosen by probing: candidates 8 GiB apart (spacer allocations in
+// between, freed afterwards), a plain copy of the input array into each, timed between two timings
+// of the first candidate; the fastest one is kept if it beats the first by more than 1 %.  Only for
+// arrays of 256 MiB and more, only while the card has the room, off with CMHIP_PLACE=0.
+constexpr size_t PLACE_MIN_BYTES = 256ull << 20;
+constexpr size_t PLACE_SPACER = 8ull << 30;
+constexpr int PLACE_TRIES = 7;
+
+static double place_probe_ms(cmhip_batch_t *b, void *dst, size_t bytes, hipEvent_t e0, hipEvent_t e1)
+{
+    const int n = 6;
+    for (int i = 0; i < 2; i++)
+        if (launch_ceiling(1, b->d_in, dst, bytes, nullptr, b->stream) != hipSuccess)
+            return -1.;
+    if (hipEventRecord(e0, b->stream) != hipSuccess)
+        return -1.;
+    for (int i = 0; i < n; i++)
+        if (launch_ceiling(1, b->d_in, dst, bytes, nullptr, b->stream) != hipSuccess)
+            return -1.;
+    float ms = 0.f;
+    if (hipEventRecord(e1, b->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+        hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+        return -1.;
+    return (double)ms / n;
+}
+
+static int alloc_output_apart(cmhip_batch_t *b, size_t bytes, int16_t **out)
+{
+    void *cand[PLACE_TRIES] = {nullptr}, *spacer[PLACE_TRIES] = {nullptr};
+    HIP_TRY(hipMalloc(&cand[0], bytes));
+    int chosen = 0;
+    size_t free_b = 0, total_b = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const size_t room = (size_t)(PLACE_TRIES - 1) * (PLACE_SPACER + bytes) + (8ull << 30);
+    if (!b->tune.place_off && bytes >= PLACE_MIN_BYTES && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+        free_b >= room && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        // (the card may come from idle: the probes compare like with like only at settled clocks)
+        for (int i = 0; i < 12; i++)
+            if (place_probe_ms(b, cand[0], bytes, e0, e1) < 0.)
+                break;
+        double best = 0.99;                               // time of a candidate over that of the first
+        for (int k = 1; k < PLACE_TRIES; k++) {
+            if (hipMalloc(&spacer[k], PLACE_SPACER) != hipSuccess || hipMalloc(&cand[k], bytes) != hipSuccess) {
+                (void)hipGetLastError();                  // no room after all: what has been seen decides
+                break;
+            }
+            const double t0a = place_probe_ms(b, cand[0], bytes, e0, e1);
+            const double tk = place_probe_ms(b, cand[k], bytes, e0, e1);
+            const double t0b = place_probe_ms(b, cand[0], bytes, e0, e1);
+            if (t0a <= 0. || tk <= 0. || t0b <= 0.)
+                break;
+            const double t0 = 0.5 * (t0a + t0b);
+            if (b->tune.place_debug)
+                fprintf(stderr, "cmhip place: candidate %d at %p: %.4f ms, first at %p: %.4f ms\n", k, cand[k], tk,
+                        cand[0], t0);
+            if (tk < best * t0) {
+                best = tk / t0;
+                chosen = k;
+            }
+        }
+    }
+    if (e0)
+        (void)hipEventDestroy(e0);
+    if (e1)
+        (void)hipEventDestroy(e1);
+    for (int k = 0; k < PLACE_TRIES; k++) {
+        if (spacer[k])
+            (void)hipFree(spacer[k]);
+        if (cand[k] && k != chosen)
+            (void)hipFree(cand[k]);
+    }
+    if (b->tune.place_debug)
+        fprintf(stderr, "cmhip place: output array = candidate %d\n", chosen);
+    *out = (int16_t *)cand[chosen];
+    return COOLMIC_ERROR_NONE;
+}
+
 static int batch_init(cmhip_batch_t *b)
 {
     const cmhip_batch_desc_t &d = b->d;
@@ -324,7 +416,8 @@ static int batch_init(cmhip_batch_t *b)
         HIP_TRY(hipMalloc((void **)&b->d_in, pcm_bytes));
         HIP_TRY(hipMemsetAsync(b->d_in, 0, pcm_bytes, b->stream));
         if ((d.flags & CMHIP_OUT_PCM) && !(d.flags & CMHIP_INPLACE)) {
-            HIP_TRY(hipMalloc((void **)&b->d_out, pcm_bytes));
+            if (alloc_output_apart(b, pcm_bytes, &b->d_out) != COOLMIC_ERROR_NONE)
+                return COOLMIC_ERROR_GENERIC;
             HIP_TRY(hipMemsetAsync(b->d_out, 0, pcm_bytes, b->stream));
         } else if (d.flags & CMHIP_OUT_PCM) {
             b->d_out = b->d_in;
@@ -451,6 +544,8 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->eq_dirty = false;
     b->nsec = 0;
     b->timing = false;
+    b->timing_every = 1;
+    b->timing_count = 0;
     b->tune = read_tune();
     b->vu_off = false;
     if (batch_init(b) != COOLMIC_ERROR_NONE) {
@@ -959,7 +1054,8 @@ static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per
 
     const bool vu = (b->d.flags & CMHIP_VU) != 0 && !b->vu_off;
     EventPair ev{};                          // timing: the events take the kernel's own start and end
-    if (b->timing) {
+    const bool timed = b->timing && b->timing_count++ % b->timing_every == 0;
+    if (timed) {
         ev = take_events(b);
     } else if (vu) {                         // the end of this run, for the next snapshot
         ev.b = b->ev_done[b->done_next];
@@ -1010,7 +1106,7 @@ static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per
         HIP_TRY(launch_run(a, b->tune, b->stream, ev.a, ev.b));
         b->in_flight = true;
     }
-    if (b->timing)
+    if (timed)
         b->ev_used.push_back(ev);
     if (vu)
         b->parity ^= 1u;                   // the kernel wrote the other samples slot
@@ -1329,6 +1425,8 @@ extern "C" int cmhip_batch_timing(cmhip_batch_t *b, int enable)
     if (!b)
         return fail(COOLMIC_ERROR_FAULT, "timing: batch is NULL");
     b->timing = enable != 0;
+    b->timing_every = enable > 1 ? (unsigned)enable : 1u;
+    b->timing_count = 0;
     return COOLMIC_ERROR_NONE;
 }
 

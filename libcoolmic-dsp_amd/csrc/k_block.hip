@@ -32,13 +32,20 @@ constexpr u32 TILE_U_VUONLY_STEREO = 16;
 // (tools/ubench_copy*.hip: 6.3-6.5 TB/s against 5.0-5.4 TB/s for read+write).
 // FULL: the tile lies completely inside the stream's whole vectors -- no bounds tests, no
 // zero padding, no ragged tail; this is the case for all but the last tile of a stream.
+// Window sums of a workgroup of several waves (FastShare, below): the waves add theirs up in LDS and the
+// last one to finish hands the workgroup's to the stream's window.
+struct FastShare {
+    u64 sum[2], key[2];
+    u32 arrived;
+};
+
 template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U, bool FULL>
 __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 nsamp, u32 nfull, u32 ntail,
-                                          u64 base, VuState *vs)
+                                          u64 base, VuState *vs, FastShare *share)
 {
     constexpr u32 TILE_U = U;
     constexpr u32 TILE_VEC = 64 * TILE_U;
-    const u32 lane = threadIdx.x;
+    const u32 lane = threadIdx.x & 63u;
     const u32 v0 = k * TILE_VEC;
     (void)nsamp;
 
@@ -246,21 +253,51 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
         if (lane < (u32)C) {                     // lane = output channel, fed by half lane ^ sw
             const u64 ssum = (lane ^ sw) == 0 ? sum[0] : sum[1];
             const u64 skey = (lane ^ sw) == 0 ? gkey[0] : gkey[1];
-            if (ssum)
-                atomicAdd(&vs->power[lane], ssum);
-            if (skey)
-                atomicMax(&vs->key[lane], skey);
+            if (share) {                         // (LDS atomics; the workgroup's last wave does the global ones)
+                if (ssum)
+                    atomicAdd(&share->sum[lane], ssum);
+                if (skey)
+                    atomicMax(&share->key[lane], skey);
+            } else {
+                if (ssum)
+                    atomicAdd(&vs->power[lane], ssum);
+                if (skey)
+                    atomicMax(&vs->key[lane], skey);
+            }
         }
     }
 }
 
-template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U>
+// NW waves per workgroup, each with a tile of its own (NW consecutive tiles of one stream).  The waves
+// share nothing while they work; with a VU window they merge their sums in LDS and whichever finishes
+// last adds the workgroup's to the window -- 1/NW of the global atomics, which are carried out far from
+// the CU and cost the one-wave form 2-8 % of a launch (tools/placement_probe10.py).
+template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U, int NW = 1>
 __device__ __forceinline__ void run_fast(const RunArgs &a)
 {
     constexpr u32 TILE_VEC = 64 * U;
-    const u32 lane = threadIdx.x;
-    const u32 s = blockIdx.x / a.chunks;         // stream
-    const u32 k = blockIdx.x - s * a.chunks;     // tile inside the stream
+    static_assert(NW == 1 || !WRITE_F32, "the float-plane forms stage through LDS with one-wave barriers");
+    const u32 lane = threadIdx.x & 63u;
+    u32 s, k;
+    if constexpr (NW == 1) {
+        s = blockIdx.x / a.chunks;               // stream
+        k = blockIdx.x - s * a.chunks;           // tile inside the stream
+    } else {
+        const u32 cw = (a.chunks + (u32)NW - 1u) / (u32)NW;      // workgroups per stream
+        s = blockIdx.x / cw;
+        k = (blockIdx.x - s * cw) * (u32)NW + (threadIdx.x >> 6);
+    }
+    __shared__ FastShare shared_;
+    FastShare *share = NW > 1 && DO_VU ? &shared_ : nullptr;
+    if constexpr (NW > 1 && DO_VU) {
+        if (threadIdx.x < 2u) {
+            shared_.sum[threadIdx.x] = 0;
+            shared_.key[threadIdx.x] = 0;
+        }
+        if (threadIdx.x == 0)
+            shared_.arrived = 0;
+        __syncthreads();                         // (the only barrier: all waves are at their start)
+    }
 
     const u32 nfr = a.nframes ? a.nframes[s] : a.frames;
     const u32 nsamp = nfr * (u32)C;
@@ -276,18 +313,35 @@ __device__ __forceinline__ void run_fast(const RunArgs &a)
         if (k == 0 && lane == 0)
             vs->samples[a.parity ^ 1u] = base + nsamp;
     }
-    if (v0 >= nfull + (ntail ? 1u : 0u))
-        return;
-    if (v0 + TILE_VEC <= nfull)
-        fast_tile<C, WRITE_PCM, WRITE_F32, DO_VU, U, true>(a, s, k, nsamp, nfull, ntail, base, vs);
-    else
-        fast_tile<C, WRITE_PCM, WRITE_F32, DO_VU, U, false>(a, s, k, nsamp, nfull, ntail, base, vs);
+    if (v0 >= nfull + (ntail ? 1u : 0u)) {
+        if constexpr (NW == 1)
+            return;
+    } else if (v0 + TILE_VEC <= nfull) {
+        fast_tile<C, WRITE_PCM, WRITE_F32, DO_VU, U, true>(a, s, k, nsamp, nfull, ntail, base, vs, share);
+    } else {
+        fast_tile<C, WRITE_PCM, WRITE_F32, DO_VU, U, false>(a, s, k, nsamp, nfull, ntail, base, vs, share);
+    }
+    if constexpr (NW > 1 && DO_VU) {
+        // LDS serves a wave's operations in order, and the waves' one after the other: the wave that counts
+        // itself last finds every other wave's sums in place
+        u32 n = 0;
+        if (lane == 0)
+            n = atomicAdd(&shared_.arrived, 1u);
+        n = (u32)__builtin_amdgcn_readfirstlane((int)n);
+        if (n == (u32)NW - 1u && lane < (u32)C) {
+            const u64 ssum = shared_.sum[lane], skey = shared_.key[lane];
+            if (ssum)
+                atomicAdd(&vs->power[lane], ssum);
+            if (skey)
+                atomicMax(&vs->key[lane], skey);
+        }
+    }
 }
 
-template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U>
-__global__ __launch_bounds__(64) void k_run_fast(RunArgs a)
+template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U, int NW = 1>
+__global__ __launch_bounds__(64 * NW) void k_run_fast(RunArgs a)
 {
-    run_fast<C, WRITE_PCM, WRITE_F32, DO_VU, U>(a);
+    run_fast<C, WRITE_PCM, WRITE_F32, DO_VU, U, NW>(a);
 }
 // The read-only entry (VU window, no PCM, no floats): at least three waves per SIMD -- the 16 KiB
 // tile holds 128 VGPRs of samples and magnitudes, and with the three arithmetic forms in one
@@ -864,6 +918,8 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
 // ---------------------------------------------------------------------------
 // Launcher of the block kernels: by channel count and by what the batch asks for.
 
+constexpr u32 FAST_NW = 4;
+
 hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const bool pcm = a.out != nullptr, f32 = a.f32 != nullptr, vu = a.vu != nullptr;
@@ -885,13 +941,30 @@ hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hip
         if ((u64)b.chunks * a.streams >= (1ull << 31))
             return hipErrorInvalidValue;
         const u32 grid = a.streams * b.chunks;
+        // Waves per workgroup of the runs that write PCM and keep a window (see run_fast).  Over 36 pairs of
+        // input and output arrays in one process, three boxes (tools/placement_probe10.py): 1 wave 0.356-0.361 ms,
+        // 2 0.348-0.357, 4 0.346-0.351, 8 0.344-0.349 on config 2 (no window: 0.327-0.332) -- but only the
+        // four-wave form also gains from arrays that lie apart (alloc_output_apart in cmhip_batch.hip:
+        // 0.333 ms, against 0.345-0.354 for eight waves and 0.340-0.351 for one).  The read-only runs
+        // (16 KiB tiles, a quarter of the atomics per byte) lose with more than one wave: 0.171 / 0.175 /
+        // 0.181 / 0.207 ms for 1 / 2 / 4 / 8.
+        const u32 nw = tune.fast_nw ? tune.fast_nw : FAST_NW;
+        const u32 gridw = a.streams * ((b.chunks + nw - 1u) / nw);
+        if ((u64)a.streams * ((b.chunks + nw - 1u) / nw) >= (1ull << 31))
+            return hipErrorInvalidValue;
 #define CMHIP_FAST(C, P, F, V, U)                                                  \
     hipExtLaunchKernelGGL((k_run_fast<C, P, F, V, U>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b)
+#define CMHIP_FAST_W(C, P, F, V, U)                                                \
+    do {                                                                           \
+        if (nw == 4) hipExtLaunchKernelGGL((k_run_fast<C, P, F, V, U, 4>), dim3(gridw), dim3(256), 0, st, ev_start, ev_stop, 0, b);        \
+        else if (nw == 8) hipExtLaunchKernelGGL((k_run_fast<C, P, F, V, U, 8>), dim3(gridw), dim3(512), 0, st, ev_start, ev_stop, 0, b);   \
+        else CMHIP_FAST(C, P, F, V, U);                                            \
+    } while (0)
 #define CMHIP_FAST_RO(C, U)                                                        \
     hipExtLaunchKernelGGL((k_run_fast_ro<C, U>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b)
 #define CMHIP_FAST_C(C)                                                            \
     do {                                                                           \
-        if (pcm && !f32 && vu) CMHIP_FAST(C, true, false, true, 4);                \
+        if (pcm && !f32 && vu) CMHIP_FAST_W(C, true, false, true, 4);              \
         else if (!pcm && !f32 && vu && tile_u == 4) CMHIP_FAST_RO(C, 4);           \
         else if (!pcm && !f32 && vu && tile_u == 8) CMHIP_FAST_RO(C, 8);           \
         else if (!pcm && !f32 && vu) CMHIP_FAST_RO(C, 16);                         \
@@ -907,6 +980,7 @@ hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hip
             CMHIP_FAST_C(2);
 #undef CMHIP_FAST_C
 #undef CMHIP_FAST_RO
+#undef CMHIP_FAST_W
 #undef CMHIP_FAST
     } else if ((a.channels == 4 || a.channels == 8) && a.identity_maps && (pcm || f32) &&
                !(a.channels == 4 && f32 && !tune.wide4_f32)) {

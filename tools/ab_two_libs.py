@@ -2,7 +2,7 @@
 """A/B of several builds of the library in ONE process, interleaved, at sustained clocks: every library
 is loaded under a module name of its own, each gets its own batch of the same shape, and timed
 blocks of launches alternate between them (process-to-process differences -- placement of the
-arrays, clocks -- cancel).  usage: ab_two_libs.py SHAPE lib1.so lib2.so ...   SHAPE: eq3 | eq3vu | eq3vu1 | eq3all | eq3vu6 | c2 | vu6"""
+arrays, clocks -- cancel).  usage: ab_two_libs.py SHAPE lib1.so lib2.so ...   SHAPE: eq3 | eq3vu | eq3vu1 | eq3all | eq3vu6 | c2 | c2s | c4 | vu1 | vu2 | vu6"""
 import importlib.util
 import os
 import sys
@@ -31,6 +31,12 @@ def make(cm, shape):
         b.set_eq(-1, cm.eq3())
         b.set_gain(-1, 1, 1000, [900])
         bps = {"eq3": 6, "eq3f2": 6, "eq3all": 8}.get(shape, 4)
+    elif shape in ("c4", "vu2", "vu1", "c2s"):       # mono PCM + VU; stereo / mono VU only; config 2 at 4096 frames
+        S, C, T = {"c4": (8192, 1, T), "vu2": (4096, 2, T), "vu1": (8192, 1, T), "c2s": (4096, 2, 4096)}[shape]
+        pcm = shape in ("c4", "c2s")
+        b = cm.Batch(S, C, T, flags=(cm.OUT_PCM | cm.VU) if pcm else cm.VU)
+        b.set_gain(-1, C, 1000, [750, 1250][:C])
+        bps = 4 if pcm else 2
     elif shape == "c2":
         S, C, bps = 4096, 2, 4
         b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU)
