@@ -271,7 +271,7 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
 // NW waves per workgroup, each with a tile of its own (NW consecutive tiles of one stream).  The waves
 // share nothing while they work; with a VU window they merge their sums in LDS and whichever finishes
 // last adds the workgroup's to the window -- 1/NW of the global atomics, which are carried out far from
-// the CU and cost the one-wave form 2-8 % of a launch (tools/placement_probe10.py).
+// the CU and cost the one-wave form 2-8 % of a launch (tools/placement_forms.py).
 template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U, int NW = 1>
 __device__ __forceinline__ void run_fast(const RunArgs &a)
 {
@@ -942,7 +942,7 @@ hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hip
             return hipErrorInvalidValue;
         const u32 grid = a.streams * b.chunks;
         // Waves per workgroup of the runs that write PCM and keep a window (see run_fast).  Over 36 pairs of
-        // input and output arrays in one process, three boxes (tools/placement_probe10.py): 1 wave 0.356-0.361 ms,
+        // input and output arrays in one process, three boxes (tools/placement_forms.py): 1 wave 0.356-0.361 ms,
         // 2 0.348-0.357, 4 0.346-0.351, 8 0.344-0.349 on config 2 (no window: 0.327-0.332) -- but only the
         // four-wave form also gains from arrays that lie apart (alloc_output_apart in cmhip_batch.hip:
         // 0.333 ms, against 0.345-0.354 for eight waves and 0.340-0.351 for one).  The read-only runs

@@ -298,6 +298,56 @@ def test_short_gain_forms_of_the_read_only_runs(gpu, oracle, C):
             b.close()
 
 
+@pytest.mark.parametrize("nw", ["1", "4", "8"])
+@pytest.mark.parametrize("C", [1, 2])
+def test_workgroups_of_several_waves_merge_their_windows(gpu, oracle, C, nw, monkeypatch):
+    """Runs that write PCM and keep a window take workgroups of four waves (a tile each) that add their
+    window sums up in LDS; the last wave to finish adds the workgroup's to the stream's window
+    (run_fast in k_block.hip; $CMHIP_FAST_NW picks 1, 4 or 8 waves).  Streams of every length around a
+    workgroup's 4 x 4 KiB -- whole workgroups, ragged last ones with idle waves, a single tile, one
+    frame, none -- with the peak in every wave's tile in turn, ties between waves (the first wins),
+    two launches per window; PCM and windows against the oracle."""
+    cm = gpu
+    monkeypatch.setenv("CMHIP_FAST_NW", nw)
+    rng = np.random.default_rng(800 + C)
+    per_tile = 2048 // C                         # frames of a 4 KiB tile
+    lens = [0, 1, per_tile - 1, per_tile, per_tile + 1, 4 * per_tile, 4 * per_tile + 3, 7 * per_tile - 5,
+            8 * per_tile, 9 * per_tile + 1, 13 * per_tile + 77]
+    T = max(lens)
+    S = len(lens)
+    gain = (C, 1000, [750, 1250][:C])
+    cmap = [1, 0] if C == 2 else None
+    xs = []
+    for s, n in enumerate(lens):
+        x = _rand_pcm(rng, T * C, "small")
+        # the same extreme magnitude in several tiles, +/-: the earliest one is the window's peak
+        for k, at in enumerate(range(s % 5, max(n, 1), max(per_tile * 2 // 3, 1))):
+            x[(at * C + k % C) % (T * C)] = 32767 if k % 2 else -32767
+        xs.append(x)
+    b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU)
+    assert b.set_gain(-1, *gain) == 0
+    if cmap:
+        assert b.set_chmap(-1, cmap) == 0
+    wants = [[], []]
+    for half in range(2):                        # two launches, one window; the second with other lengths
+        ls = lens if half == 0 else lens[::-1]
+        for s in range(S):
+            b.upload(s, xs[s] if half == 0 else xs[s][::-1].copy())
+        b.run(T, frames_per_stream=ls)
+        for s in range(S):
+            src = (xs[s] if half == 0 else xs[s][::-1])[:ls[s] * C]
+            want = _oracle_block(oracle, src, C, gain, cmap)
+            wants[half].append(want)
+            got = b.download(s, ls[s]) if ls[s] else np.zeros(0, np.int16)
+            assert np.array_equal(got, want), (C, nw, half, s)
+    for s in range(S):
+        rc, r = b.vu_result(s)
+        blocks = [w for w in (wants[0][s], wants[1][s]) if len(w)]
+        _, ro = _oracle_vu(oracle, blocks, C)
+        assert rc == 0 and r.as_dict() == of.vu_result_dict(ro), (C, nw, s)
+    b.close()
+
+
 @pytest.mark.parametrize("C", [3, 4, 6, 8, 13, 16])
 def test_many_channel_read_only_runs_without_gain(gpu, oracle, C):
     """A batch in which no stream has a gain (the transform as the reference creates it, or unity

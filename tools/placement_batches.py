@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Is the 6 % spread of the config-2 kernel between processes a property of where its arrays lie?
 Several batches of the config-2 shape in ONE process, timed in interleaved blocks of launches (kernel time
-from the dispatch's own events).  usage: placement_probe.py [batches] [rounds]"""
+from the dispatch's own events).  usage: placement_batches.py [batches] [rounds]"""
 import importlib
 import os
 import sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Classes of placement inside one slab (placement_probe6): inputs at several offsets x outputs every STEP GiB.
+"""Classes of placement inside one slab (placement_slab): inputs at several offsets x outputs every STEP GiB.
 A pair is slow when both arrays are in the same class; the rows show which stretches of the slab share one."""
 import ctypes as C
 import importlib

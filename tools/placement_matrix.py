@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""placement_probe2's question as a matrix: N input arrays x N output arrays (separate hipMallocs), the config-2
+"""Where the arrays lie against the speed of the config-2 kernel, as a matrix: N input arrays x N output arrays (separate hipMallocs), the config-2
 kernel on every pair.  Does the time follow the input array, the output array, or the pair?"""
 import ctypes as C
 import importlib

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""One large slab, input at its start, output k GiB further on: is the placement class (placement_probe3/4)
-periodic in the distance?  usage: placement_probe6.py [slab GiB] [step MiB]"""
+"""One large slab, input at its start, output k GiB further on: is the placement class (placement_matrix/4)
+periodic in the distance?  usage: placement_slab.py [slab GiB] [step MiB]"""
 import ctypes as C
 import importlib
 import os
