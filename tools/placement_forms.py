@@ -13,7 +13,7 @@ cm = importlib.import_module("libcoolmic-dsp_amd")
 hip = C.CDLL("libamdhip64.so")
 hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
 hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-S, Cn, T = 4096, 2, 65536
+S, Cn, T = [int(x) for x in os.environ.get("PF_SHAPE", "4096,2,65536").split(",")]    # e.g. PF_SHAPE=2730,6,16384
 BYTES = S * Cn * T * 2
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 
@@ -30,8 +30,11 @@ def make(flags, env=None):
     b = cm.Batch(S, Cn, T, flags=flags | cm.EXTSLOTS)
     if env:
         os.environ.pop(env[0])
-    b.set_gain(-1, 2, 1000, [750, 1250])
-    b.set_chmap(-1, [1, 0])
+    if Cn == 2:
+        b.set_gain(-1, 2, 1000, [750, 1250])
+        b.set_chmap(-1, [1, 0])
+    else:
+        b.set_gain(-1, 1, 1000, [900])
     return b
 
 
@@ -49,8 +52,11 @@ for extra in sys.argv[3:]:                # other builds of the library (timing-
     sys.modules[tag] = cm2
     spec.loader.exec_module(cm2)
     b2 = cm2.Batch(S, Cn, T, flags=(cm2.VU if RO else cm2.OUT_PCM | cm2.VU) | cm2.EXTSLOTS)
-    b2.set_gain(-1, 2, 1000, [750, 1250])
-    b2.set_chmap(-1, [1, 0])
+    if Cn == 2:
+        b2.set_gain(-1, 2, 1000, [750, 1250])
+        b2.set_chmap(-1, [1, 0])
+    else:
+        b2.set_gain(-1, 1, 1000, [900])
     forms.append((os.path.basename(extra)[-24:], b2))
 host = np.random.default_rng(1).integers(-32768, 32767, size=BYTES // 2, dtype=np.int16)
 arr = [dmalloc(BYTES) for _ in range(2 * N)]
