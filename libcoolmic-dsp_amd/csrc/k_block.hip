@@ -324,10 +324,14 @@ __device__ __forceinline__ void run_fast(const RunArgs &a)
     if constexpr (NW > 1 && DO_VU) {
         // LDS serves a wave's operations in order, and the waves' one after the other: the wave that counts
         // itself last finds every other wave's sums in place
+        // (the hardware keeps that order; the waits and the "memory" clobbers keep the compiler from moving
+        // this wave's sums behind its count, or the last wave's reads ahead of it)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         u32 n = 0;
         if (lane == 0)
             n = atomicAdd(&shared_.arrived, 1u);
         n = (u32)__builtin_amdgcn_readfirstlane((int)n);
+        asm volatile("" ::: "memory");
         if (n == (u32)NW - 1u && lane < (u32)C) {
             const u64 ssum = shared_.sum[lane], skey = shared_.key[lane];
             if (ssum)
