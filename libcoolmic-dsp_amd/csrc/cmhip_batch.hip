@@ -443,7 +443,16 @@ static int batch_init(cmhip_batch_t *b)
         HIP_TRY(hipEventCreateWithFlags(&b->ev_reset[i], hipEventDisableTiming));
     }
     b->d_vu = b->d_vu2[0];
-    HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+    {
+        // The copy stream carries small work beside the main stream's long kernels (snapshots, node
+        // records): at the highest priority, or its kernels wait for a slot among a quarter of a million
+        // workgroups of the run (config 5: k_node_partial took 30-330 us instead of 9, and every few
+        // steps the chain snapshot -> collect -> next launch left the card idle for 150 us)
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&b->copy_stream, hipStreamNonBlocking,
+                                            getenv("CMHIP_SIDE_PRIORITY_OFF") ? least : greatest));
+    }
     HIP_TRY(hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&b->ev_node, hipEventDisableTiming));
     for (int i = 0; i < 4; i++)

@@ -109,61 +109,53 @@ __device__ __forceinline__ u64 wave_max(u64 v)
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_node_partial(const VuState *vu, u32 streams, u32 channels,
-                                                      u32 parity, u64 first_global, u64 global_step,
-                                                      long long *dst_sum, long long *dst_key)
+// NC: the batch's channel count or an upper bound of it (1, 2, MAX_CH) -- the record has MAX_CH + 1 slots, a
+// mono or stereo batch fills two or three of them, and the kernel runs beside the batch's next run, where
+// every instruction it does not execute counts (config 5: 17 slots reduced for one channel took 30-300 us
+// there instead of 9 alone).  One wave per workgroup: it takes whatever slot a CU has free.
+template <u32 NC>
+__global__ __launch_bounds__(64) void k_node_partial(const VuState *vu, u32 streams, u32 channels,
+                                                     u32 parity, u64 first_global, u64 global_step,
+                                                     long long *dst_sum, long long *dst_key)
 {
-    __shared__ u64 lsum[MAX_CH + 1];
-    __shared__ u64 lkey[MAX_CH + 1];
-    if (threadIdx.x <= MAX_CH) {
-        lsum[threadIdx.x] = 0;
-        lkey[threadIdx.x] = 0;
-    }
-    __syncthreads();
-    u64 sum[MAX_CH + 1], key[MAX_CH + 1];
+    u64 sum[NC + 1], key[NC + 1];                // [NC]: frames / the peak over all channels
 #pragma unroll
-    for (u32 c = 0; c <= MAX_CH; c++) {
+    for (u32 c = 0; c <= NC; c++) {
         sum[c] = 0;
         key[c] = 0;
     }
-    for (u32 s = blockIdx.x * 256u + threadIdx.x; s < streams; s += gridDim.x * 256u) {
+    for (u32 s = blockIdx.x * 64u + threadIdx.x; s < streams; s += gridDim.x * 64u) {
         const u64 gs = first_global + (u64)s * global_step;
-        sum[MAX_CH] += vu[s].samples[parity] / channels;
+        sum[NC] += NC == 1 ? vu[s].samples[parity] : vu[s].samples[parity] / channels;
 #pragma unroll
-        for (u32 c = 0; c < MAX_CH; c++) {
+        for (u32 c = 0; c < NC; c++) {
             if (c < channels) {
                 sum[c] += vu[s].power[c];
                 const u64 k0 = vu[s].key[c];
                 if (k0) {
                     const u64 mag = k0 >> KEY_ABS_SHIFT;
                     const u64 idx = ~(k0 >> 1) & KEY_IDX_MASK;
-                    u64 fr = idx / channels;
+                    u64 fr = NC == 1 ? idx : NC == 2 ? (channels == 2 ? idx >> 1 : idx) : idx / channels;
                     fr = fr > 0x1fffffffull ? 0x1fffffffull : fr;
                     const u64 nk = (mag << 46) | ((0x1fffffffull - fr) << 17) |
                                    ((65535ull - (gs & 65535ull)) << 1) | (k0 & 1ull);
                     key[c] = nk > key[c] ? nk : key[c];
-                    key[MAX_CH] = nk > key[MAX_CH] ? nk : key[MAX_CH];
+                    key[NC] = nk > key[NC] ? nk : key[NC];
                 }
             }
         }
     }
 #pragma unroll
-    for (u32 c = 0; c <= MAX_CH; c++) {
+    for (u32 c = 0; c <= NC; c++) {
         const u64 ws = wave_sum(sum[c]);
         const u64 wk = wave_max(key[c]);
-        if ((threadIdx.x & 63u) == 0) {
+        const u32 slot = c == NC ? (u32)MAX_CH : c;
+        if (threadIdx.x == 0 && (c == NC || c < channels)) {
             if (ws)
-                atomicAdd(&lsum[c], ws);
+                atomicAdd(reinterpret_cast<u64 *>(dst_sum) + slot, ws);
             if (wk)
-                atomicMax(&lkey[c], wk);
+                atomicMax(reinterpret_cast<u64 *>(dst_key) + slot, wk);
         }
-    }
-    __syncthreads();
-    if (threadIdx.x <= MAX_CH) {
-        if (lsum[threadIdx.x])
-            atomicAdd(reinterpret_cast<u64 *>(dst_sum) + threadIdx.x, lsum[threadIdx.x]);
-        if (lkey[threadIdx.x])
-            atomicMax(reinterpret_cast<u64 *>(dst_key) + threadIdx.x, lkey[threadIdx.x]);
     }
 }
 
@@ -179,11 +171,18 @@ hipError_t launch_node_partial(const VuState *vu, u32 streams, u32 channels, u32
         if (e != hipSuccess)
             return e;
     }
-    u32 grid = (streams + 255) / 256;
-    if (grid > 256)
-        grid = 256;
-    hipExtLaunchKernelGGL(k_node_partial, dim3(grid), dim3(256), 0, st, nullptr, ev_stop, 0, vu, streams, channels,
-                          parity, first_global, global_step, dst_sum, dst_key);
+    u32 grid = (streams + 63) / 64;
+    if (grid > 1024)
+        grid = 1024;
+    if (channels == 1)
+        hipExtLaunchKernelGGL(k_node_partial<1>, dim3(grid), dim3(64), 0, st, nullptr, ev_stop, 0, vu, streams, channels,
+                              parity, first_global, global_step, dst_sum, dst_key);
+    else if (channels == 2)
+        hipExtLaunchKernelGGL(k_node_partial<2>, dim3(grid), dim3(64), 0, st, nullptr, ev_stop, 0, vu, streams, channels,
+                              parity, first_global, global_step, dst_sum, dst_key);
+    else
+        hipExtLaunchKernelGGL(k_node_partial<MAX_CH>, dim3(grid), dim3(64), 0, st, nullptr, ev_stop, 0, vu, streams,
+                              channels, parity, first_global, global_step, dst_sum, dst_key);
     return hipGetLastError();
 }
 

@@ -168,7 +168,12 @@ extern "C" void cmhip_node_free(cmhip_node_t *n)
 static int node_init(cmhip_node_t *n, const Rccl *rc, const void *id128)
 {
     HIP_TRY(hipSetDevice(n->device));
-    HIP_TRY(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
+    {
+        int least = 0, greatest = 0;             // (beside the batches' long kernels: see their copy streams)
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&n->stream, hipStreamNonBlocking,
+                                            getenv("CMHIP_SIDE_PRIORITY_OFF") ? least : greatest));
+    }
     const size_t bytes = (size_t)NODE_SETS * 2u * HALF * n->max_records * sizeof(long long);
     HIP_TRY(hipMalloc((void **)&n->d_words, bytes));
     HIP_TRY(hipMemset(n->d_words, 0, bytes));
