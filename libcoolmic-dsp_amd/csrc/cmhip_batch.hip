@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -165,8 +166,10 @@ static RunTune read_tune()
         if (v == 1 || v == 4 || v == 8)
             t.fast_nw = (uint32_t)v;
     }
-    if (const char *e = getenv("CMHIP_PLACE"))
+    if (const char *e = getenv("CMHIP_PLACE")) {
         t.place_off = atoi(e) == 0 ? 1u : 0u;
+        t.place_always = atoi(e) == 2 ? 1u : 0u;
+    }
     if (getenv("CMHIP_PLACE_DEBUG"))
         t.place_debug = 1;
     return t;
@@ -301,13 +304,19 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
 // tools/placement_*.py, DESIGN 4.1 -- physical memory falls into stretches of up to 32 GiB of
 // three kinds; reads and writes that go to the same kind get in each other's way, and of the pairs
 // of different kinds some are better than others).  Nothing but the virtual address is visible from
-// here, so the output array is chosen by probing: candidates 8 GiB apart (spacer allocations in
+// here, so the output array is chosen by probing: candidates 4 to 32 GiB apart (spacer allocations in
 // between, freed afterwards), a plain copy of the input array into each, timed between two timings
-// of the first candidate; the fastest one is kept if it beats the first by more than 1 %.  Only for
-// arrays of 256 MiB and more, only while the card has the room and within 0.3 s, off with CMHIP_PLACE=0.
+// of the first candidate; the fastest one is kept if it beats the first by more than 2.5 %.  Only for
+// arrays of 256 MiB and more, only while the card has the room and within 0.3 s, once per device and
+// process (place_search_allowed), off with CMHIP_PLACE=0.
 constexpr size_t PLACE_MIN_BYTES = 256ull << 20;
-constexpr size_t PLACE_SPACER = 8ull << 30;
-constexpr int PLACE_TRIES = 7;
+// Spacers before candidates 1, 2, ...: 40 GiB in all reach past one whole stretch.  (Larger ones reach further
+// -- 4 ... 32 GiB, 124 in all, found the best kind of pair more often -- but allocating from memory that this or
+// an earlier process has freed is slow on this driver, which hands out cleared pages: single allocations of
+// 16-32 GiB were seen to take 3-6 s.)
+constexpr size_t PLACE_SPACER_GIB[] = {0, 4, 8, 12, 16};
+constexpr int PLACE_TRIES = 5;
+constexpr size_t PLACE_SPACER_SUM = (4ull + 8 + 12 + 16) << 30;
 constexpr double PLACE_BUDGET_S = 0.3;
 
 static double place_probe_ms(cmhip_batch_t *b, void *dst, size_t bytes, hipEvent_t e0, hipEvent_t e1)
@@ -328,6 +337,24 @@ static double place_probe_ms(cmhip_batch_t *b, void *dst, size_t bytes, hipEvent
     return (double)ms / n;
 }
 
+// One search per device and process (CMHIP_PLACE=2: for every batch): the spacers are 40 GiB that go back to
+// the driver, and allocating from memory the process has freed is slow on this driver (see PLACE_SPACER_GIB).
+static bool place_search_allowed(const cmhip_batch_t *b)
+{
+    static std::mutex mu;
+    static bool searched[64];
+    if (b->tune.place_off)
+        return false;
+    if (b->tune.place_always)
+        return true;
+    std::lock_guard<std::mutex> g(mu);
+    const int d = b->d.device;
+    if (d < 0 || d >= 64 || searched[d])
+        return false;
+    searched[d] = true;
+    return true;
+}
+
 static int alloc_output_apart(cmhip_batch_t *b, size_t bytes, int16_t **out)
 {
     void *cand[PLACE_TRIES] = {nullptr}, *spacer[PLACE_TRIES] = {nullptr};
@@ -335,21 +362,23 @@ static int alloc_output_apart(cmhip_batch_t *b, size_t bytes, int16_t **out)
     int chosen = 0;
     size_t free_b = 0, total_b = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const size_t room = (size_t)(PLACE_TRIES - 1) * (PLACE_SPACER + bytes) + (8ull << 30);
-    if (!b->tune.place_off && bytes >= PLACE_MIN_BYTES && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+    const size_t room = PLACE_SPACER_SUM + (size_t)(PLACE_TRIES - 1) * bytes + (8ull << 30);
+    if (bytes >= PLACE_MIN_BYTES && place_search_allowed(b) && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
         free_b >= room && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         // (the card may come from idle: the probes compare like with like only at settled clocks)
         for (int i = 0; i < 12; i++)
             if (place_probe_ms(b, cand[0], bytes, e0, e1) < 0.)
                 break;
-        double best = 0.99;                               // time of a candidate over that of the first
+        // (only the best kind of pair is worth taking: its copy is 3-7 % faster than the first candidate's;
+        // differences of 1-2 % between candidates do not show in the run)
+        double best = 0.975;                              // time of a candidate over that of the first
         const auto t_begin = std::chrono::steady_clock::now();
         for (int k = 1; k < PLACE_TRIES; k++) {
             // (allocations of this size are normally a few milliseconds; in a process that has freed and
             // allocated many of them the driver has been seen to take seconds: then what is known decides)
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > PLACE_BUDGET_S)
                 break;
-            if (hipMalloc(&spacer[k], PLACE_SPACER) != hipSuccess || hipMalloc(&cand[k], bytes) != hipSuccess) {
+            if (hipMalloc(&spacer[k], PLACE_SPACER_GIB[k] << 30) != hipSuccess || hipMalloc(&cand[k], bytes) != hipSuccess) {
                 (void)hipGetLastError();                  // no room after all: what has been seen decides
                 break;
             }
@@ -360,8 +389,9 @@ static int alloc_output_apart(cmhip_batch_t *b, size_t bytes, int16_t **out)
                 break;
             const double t0 = 0.5 * (t0a + t0b);
             if (b->tune.place_debug)
-                fprintf(stderr, "cmhip place: candidate %d at %p: %.4f ms, first at %p: %.4f ms\n", k, cand[k], tk,
-                        cand[0], t0);
+                fprintf(stderr, "cmhip place: candidate %d at %p: %.4f ms, first at %p: %.4f ms  (%.0f ms into the search)\n",
+                        k, cand[k], tk, cand[0], t0,
+                        1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
             if (tk < best * t0) {
                 best = tk / t0;
                 chosen = k;
@@ -372,6 +402,7 @@ static int alloc_output_apart(cmhip_batch_t *b, size_t bytes, int16_t **out)
         (void)hipEventDestroy(e0);
     if (e1)
         (void)hipEventDestroy(e1);
+    const auto t_free = std::chrono::steady_clock::now();
     for (int k = 0; k < PLACE_TRIES; k++) {
         if (spacer[k])
             (void)hipFree(spacer[k]);
@@ -379,7 +410,8 @@ static int alloc_output_apart(cmhip_batch_t *b, size_t bytes, int16_t **out)
             (void)hipFree(cand[k]);
     }
     if (b->tune.place_debug)
-        fprintf(stderr, "cmhip place: output array = candidate %d\n", chosen);
+        fprintf(stderr, "cmhip place: output array = candidate %d (the frees took %.0f ms)\n", chosen,
+                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_free).count());
     *out = (int16_t *)cand[chosen];
     return COOLMIC_ERROR_NONE;
 }

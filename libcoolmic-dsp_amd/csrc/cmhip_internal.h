@@ -94,6 +94,7 @@ struct RunTune {
     uint32_t rows_rpt;
     uint32_t fast_nw;              // CMHIP_FAST_NW in {1, 4, 8}: waves per workgroup of the mono / stereo forms with a window
     uint32_t place_off;            // CMHIP_PLACE=0: the PCM output array stays where hipMalloc first puts it
+    uint32_t place_always;         // CMHIP_PLACE=2: search for every batch, not only the first of a device
     uint32_t place_debug;          // CMHIP_PLACE_DEBUG: the probe times of the placement search on stderr
 };
 

@@ -9,7 +9,7 @@ timeout -k 10 400 python tools/placement_matrix.py 6 > gpurun_out/placement_matr
 timeout -k 10 400 python tools/placement_forms.py 6 > gpurun_out/placement_forms.txt 2>&1
 timeout -k 10 400 python tools/placement_forms.py 3 ro > gpurun_out/placement_forms_ro.txt 2>&1
 for nw in 4 8 1; do
-    echo "CMHIP_FAST_NW=$nw, placement search on"; CMHIP_FAST_NW=$nw CMHIP_PLACE_DEBUG=1 timeout -k 10 300 python tools/placement_batches.py 6 2 2>&1 | grep -v "candidate [0-9] at"
+    echo "CMHIP_FAST_NW=$nw, placement search on"; CMHIP_PLACE=2 CMHIP_FAST_NW=$nw CMHIP_PLACE_DEBUG=1 timeout -k 10 300 python tools/placement_batches.py 6 2 2>&1 | grep -v "candidate [0-9] at"
     echo "CMHIP_FAST_NW=$nw, CMHIP_PLACE=0"; CMHIP_PLACE=0 CMHIP_FAST_NW=$nw timeout -k 10 300 python tools/placement_batches.py 6 2 2>&1
 done > gpurun_out/placement_batches.txt
 timeout -k 10 300 python tools/step_overhead.py > gpurun_out/step_overhead.txt 2>&1
