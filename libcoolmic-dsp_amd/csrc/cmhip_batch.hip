@@ -305,7 +305,7 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
 // three kinds; reads and writes that go to the same kind get in each other's way, and of the pairs
 // of different kinds some are better than others).  Nothing but the virtual address is visible from
 // here, so the output array is chosen by probing: candidates 4 to 32 GiB apart (spacer allocations in
-// between, freed afterwards), a plain copy of the input array into each, timed between two timings
+// between, freed afterwards), the batch's own run into each, timed between two timings
 // of the first candidate; the fastest one is kept if it beats the first by more than 2.5 %.  Only for
 // arrays of 256 MiB and more, only while the card has the room and within 0.3 s, once per device and
 // process (place_search_allowed), off with CMHIP_PLACE=0.
@@ -319,16 +319,32 @@ constexpr int PLACE_TRIES = 5;
 constexpr size_t PLACE_SPACER_SUM = (4ull + 8 + 12 + 16) << 30;
 constexpr double PLACE_BUDGET_S = 0.3;
 
-static double place_probe_ms(cmhip_batch_t *b, void *dst, size_t bytes, hipEvent_t e0, hipEvent_t e1)
+// a probe: the batch's own run (as created: no gain, no maps), full slots, into the candidate
+static double place_probe_ms(cmhip_batch_t *b, void *dst, hipEvent_t e0, hipEvent_t e1)
 {
+    RunArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = b->d_in;
+    a.out = (int16_t *)dst;
+    a.f32 = b->d_f32;
+    a.param = b->d_param;
+    a.gshort = b->d_gshort;
+    a.vu = (b->d.flags & CMHIP_VU) ? b->d_vu : nullptr;
+    a.frames = (uint32_t)b->d.max_frames;
+    a.streams = b->d.streams;
+    a.channels = b->d.channels;
+    a.stride = b->stride;
+    a.plane = b->plane;
+    a.identity_maps = 1;
+    a.identity_gains = 1;
     const int n = 6;
     for (int i = 0; i < 2; i++)
-        if (launch_ceiling(1, b->d_in, dst, bytes, nullptr, b->stream) != hipSuccess)
+        if (launch_run(a, b->tune, b->stream) != hipSuccess)
             return -1.;
     if (hipEventRecord(e0, b->stream) != hipSuccess)
         return -1.;
     for (int i = 0; i < n; i++)
-        if (launch_ceiling(1, b->d_in, dst, bytes, nullptr, b->stream) != hipSuccess)
+        if (launch_run(a, b->tune, b->stream) != hipSuccess)
             return -1.;
     float ms = 0.f;
     if (hipEventRecord(e1, b->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
@@ -355,19 +371,23 @@ static bool place_search_allowed(const cmhip_batch_t *b)
     return true;
 }
 
-static int alloc_output_apart(cmhip_batch_t *b, size_t bytes, int16_t **out)
+static int flush_params(cmhip_batch_t *b);
+
+static int place_output_apart(cmhip_batch_t *b, size_t bytes)
 {
+    bool probed = false;
     void *cand[PLACE_TRIES] = {nullptr}, *spacer[PLACE_TRIES] = {nullptr};
-    HIP_TRY(hipMalloc(&cand[0], bytes));
+    cand[0] = b->d_out;                                   // where hipMalloc first put it
     int chosen = 0;
     size_t free_b = 0, total_b = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const size_t room = PLACE_SPACER_SUM + (size_t)(PLACE_TRIES - 1) * bytes + (8ull << 30);
     if (bytes >= PLACE_MIN_BYTES && place_search_allowed(b) && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
         free_b >= room && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        probed = true;
         // (the card may come from idle: the probes compare like with like only at settled clocks)
         for (int i = 0; i < 12; i++)
-            if (place_probe_ms(b, cand[0], bytes, e0, e1) < 0.)
+            if (place_probe_ms(b, cand[0], e0, e1) < 0.)
                 break;
         // (only the best kind of pair is worth taking: its copy is 3-7 % faster than the first candidate's;
         // differences of 1-2 % between candidates do not show in the run)
@@ -382,9 +402,9 @@ static int alloc_output_apart(cmhip_batch_t *b, size_t bytes, int16_t **out)
                 (void)hipGetLastError();                  // no room after all: what has been seen decides
                 break;
             }
-            const double t0a = place_probe_ms(b, cand[0], bytes, e0, e1);
-            const double tk = place_probe_ms(b, cand[k], bytes, e0, e1);
-            const double t0b = place_probe_ms(b, cand[0], bytes, e0, e1);
+            const double t0a = place_probe_ms(b, cand[0], e0, e1);
+            const double tk = place_probe_ms(b, cand[k], e0, e1);
+            const double t0b = place_probe_ms(b, cand[0], e0, e1);
             if (t0a <= 0. || tk <= 0. || t0b <= 0.)
                 break;
             const double t0 = 0.5 * (t0a + t0b);
@@ -412,7 +432,18 @@ static int alloc_output_apart(cmhip_batch_t *b, size_t bytes, int16_t **out)
     if (b->tune.place_debug)
         fprintf(stderr, "cmhip place: output array = candidate %d (the frees took %.0f ms)\n", chosen,
                 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_free).count());
-    *out = (int16_t *)cand[chosen];
+    if (chosen != 0) {
+        b->d_out = (int16_t *)cand[chosen];
+        HIP_TRY(hipMemsetAsync(b->d_out, 0, bytes, b->stream));
+    }
+    // the probes ran the batch's kernel: whatever they left in the windows and the float planes goes
+    if (!probed)
+        return COOLMIC_ERROR_NONE;
+    if (b->d.flags & CMHIP_VU)
+        for (int i = 0; i < 3; i++)
+            HIP_TRY(hipMemsetAsync(b->d_vu2[i], 0, b->d.streams * sizeof(VuState), b->stream));
+    if (b->d_f32)
+        HIP_TRY(hipMemsetAsync(b->d_f32, 0, b->d.streams * b->d.channels * b->plane * sizeof(float), b->stream));
     return COOLMIC_ERROR_NONE;
 }
 
@@ -455,8 +486,7 @@ static int batch_init(cmhip_batch_t *b)
         HIP_TRY(hipMalloc((void **)&b->d_in, pcm_bytes));
         HIP_TRY(hipMemsetAsync(b->d_in, 0, pcm_bytes, b->stream));
         if ((d.flags & CMHIP_OUT_PCM) && !(d.flags & CMHIP_INPLACE)) {
-            if (alloc_output_apart(b, pcm_bytes, &b->d_out) != COOLMIC_ERROR_NONE)
-                return COOLMIC_ERROR_GENERIC;
+            HIP_TRY(hipMalloc((void **)&b->d_out, pcm_bytes));
             HIP_TRY(hipMemsetAsync(b->d_out, 0, pcm_bytes, b->stream));
         } else if (d.flags & CMHIP_OUT_PCM) {
             b->d_out = b->d_in;
@@ -518,6 +548,11 @@ static int batch_init(cmhip_batch_t *b)
         for (unsigned c = 0; c < MAX_CH; c++)
             b->h_param[s].chmap[c] = (uint8_t)(c < d.channels ? c : 0);
         rebuild_param(b, (unsigned)s);
+    }
+    // a separate PCM output array of its own: where it lies against the input array (place_output_apart)
+    if (b->d_out && b->d_out != b->d_in && !(d.flags & (CMHIP_HOSTPCM | CMHIP_EXTSLOTS | CMHIP_EQ))) {
+        if (flush_params(b) || place_output_apart(b, pcm_bytes))
+            return COOLMIC_ERROR_GENERIC;
     }
     HIP_TRY(hipStreamSynchronize(b->stream));
     return COOLMIC_ERROR_NONE;
