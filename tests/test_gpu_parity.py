@@ -961,3 +961,28 @@ def test_run_on_slot_arrays_named_per_run(gpu, oracle):
     for m in ins + outs:
         m.free()
     b.close()
+
+
+def test_kernel_timing_on_every_launch_and_on_a_sample(gpu):
+    """`cmhip_batch_timing(b, 1)` stamps events on every run, `(b, n)` on every n-th (what `bench.py` uses:
+    the events cost a run about 5 us of its stream's time); `timing_read` returns their sum and count and
+    starts over."""
+    cm = gpu
+    b = cm.Batch(8, 2, 4096, flags=cm.OUT_PCM | cm.VU)
+    b.generate(cm.GEN_NOISE, 1, 4096)
+    b.timing(True)
+    for _ in range(6):
+        b.run(4096)
+    ms, n = b.timing_read()
+    assert n == 6 and 0 < ms < 100
+    b.timing(4)
+    for _ in range(10):                          # runs 0, 4, 8 of these carry the events
+        b.run(4096)
+    ms, n = b.timing_read()
+    assert n == 3 and 0 < ms < 100
+    ms, n = b.timing_read()
+    assert n == 0 and ms == 0
+    b.timing(False)
+    b.run(4096)
+    assert b.timing_read()[1] == 0
+    b.close()
