@@ -319,12 +319,12 @@ constexpr int PLACE_TRIES = 5;
 constexpr size_t PLACE_SPACER_SUM = (4ull + 8 + 12 + 16) << 30;
 constexpr double PLACE_BUDGET_S = 0.3;
 
-// a probe: the batch's own run (as created: no gain, no maps), full slots, into the candidate
-static double place_probe_ms(cmhip_batch_t *b, void *dst, hipEvent_t e0, hipEvent_t e1)
+// a probe: the batch's own run (as created: no gain, no maps), full slots, from one candidate into another
+static double place_probe_ms(cmhip_batch_t *b, const void *src, void *dst, hipEvent_t e0, hipEvent_t e1)
 {
     RunArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = b->d_in;
+    a.in = (const int16_t *)src;
     a.out = (int16_t *)dst;
     a.f32 = b->d_f32;
     a.param = b->d_param;
@@ -373,72 +373,75 @@ static bool place_search_allowed(const cmhip_batch_t *b)
 
 static int flush_params(cmhip_batch_t *b);
 
-static int place_output_apart(cmhip_batch_t *b, size_t bytes)
+// The batch has its two PCM arrays where hipMalloc first put them (candidates 0 and 1).  More candidates
+// follow behind spacers; every pair of candidates is a possible (input, output) -- nothing is in the arrays
+// yet -- and the pair the batch's own run is fastest on is kept if it beats the first by more than 2.5 %.
+static int place_arrays_apart(cmhip_batch_t *b, size_t bytes)
 {
     bool probed = false;
-    void *cand[PLACE_TRIES] = {nullptr}, *spacer[PLACE_TRIES] = {nullptr};
-    cand[0] = b->d_out;                                   // where hipMalloc first put it
-    int chosen = 0;
+    void *cand[PLACE_TRIES + 1] = {nullptr}, *spacer[PLACE_TRIES + 1] = {nullptr};
+    cand[0] = b->d_in;
+    cand[1] = b->d_out;
+    int n = 2, in = 0, out = 1;
     size_t free_b = 0, total_b = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const size_t room = PLACE_SPACER_SUM + (size_t)(PLACE_TRIES - 1) * bytes + (8ull << 30);
     if (bytes >= PLACE_MIN_BYTES && place_search_allowed(b) && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
         free_b >= room && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         probed = true;
+        // (allocations of this size are normally a few milliseconds; from memory that has been used and freed
+        // the driver has been seen to take seconds: then what there is by then decides)
+        const auto t_begin = std::chrono::steady_clock::now();
+        auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+        for (int k = 1; k < PLACE_TRIES && elapsed() <= PLACE_BUDGET_S; k++) {
+            if (hipMalloc(&spacer[n], PLACE_SPACER_GIB[k] << 30) != hipSuccess || hipMalloc(&cand[n], bytes) != hipSuccess) {
+                (void)hipGetLastError();                  // no room after all
+                break;
+            }
+            n++;
+        }
         // (the card may come from idle: the probes compare like with like only at settled clocks)
         for (int i = 0; i < 12; i++)
-            if (place_probe_ms(b, cand[0], e0, e1) < 0.)
+            if (place_probe_ms(b, cand[0], cand[1], e0, e1) < 0.)
                 break;
-        // (only the best kind of pair is worth taking: its copy is 3-7 % faster than the first candidate's;
-        // differences of 1-2 % between candidates do not show in the run)
-        double best = 0.975;                              // time of a candidate over that of the first
-        const auto t_begin = std::chrono::steady_clock::now();
-        for (int k = 1; k < PLACE_TRIES; k++) {
-            // (allocations of this size are normally a few milliseconds; in a process that has freed and
-            // allocated many of them the driver has been seen to take seconds: then what is known decides)
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > PLACE_BUDGET_S)
-                break;
-            if (hipMalloc(&spacer[k], PLACE_SPACER_GIB[k] << 30) != hipSuccess || hipMalloc(&cand[k], bytes) != hipSuccess) {
-                (void)hipGetLastError();                  // no room after all: what has been seen decides
-                break;
-            }
-            const double t0a = place_probe_ms(b, cand[0], e0, e1);
-            const double tk = place_probe_ms(b, cand[k], e0, e1);
-            const double t0b = place_probe_ms(b, cand[0], e0, e1);
-            if (t0a <= 0. || tk <= 0. || t0b <= 0.)
-                break;
-            const double t0 = 0.5 * (t0a + t0b);
-            if (b->tune.place_debug)
-                fprintf(stderr, "cmhip place: candidate %d at %p: %.4f ms, first at %p: %.4f ms  (%.0f ms into the search)\n",
-                        k, cand[k], tk, cand[0], t0,
-                        1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
-            if (tk < best * t0) {
-                best = tk / t0;
-                chosen = k;
+        // (only the best kind of pair is worth taking: 3-7 % faster than a pair of one kind; differences of
+        // 1-2 % between pairs do not last)
+        double best = 0.975;                              // time of a pair over that of the first
+        for (int i = 0; i < n; i++) {
+            const double ref = place_probe_ms(b, cand[0], cand[1], e0, e1);     // (again per row: clocks drift)
+            for (int j = i + 1; j < n && ref > 0.; j++) {
+                if (i == 0 && j == 1)
+                    continue;
+                const double t = place_probe_ms(b, cand[i], cand[j], e0, e1);
+                if (b->tune.place_debug)
+                    fprintf(stderr, "cmhip place: %d -> %d: %.4f ms (0 -> 1: %.4f ms)\n", i, j, t, ref);
+                if (t > 0. && t < best * ref) {
+                    best = t / ref;
+                    in = i;
+                    out = j;
+                }
             }
         }
+        if (b->tune.place_debug)
+            fprintf(stderr, "cmhip place: input = candidate %d, output = candidate %d, %.0f ms\n", in, out, 1e3 * elapsed());
     }
     if (e0)
         (void)hipEventDestroy(e0);
     if (e1)
         (void)hipEventDestroy(e1);
-    const auto t_free = std::chrono::steady_clock::now();
-    for (int k = 0; k < PLACE_TRIES; k++) {
+    for (int k = 0; k < n; k++) {
         if (spacer[k])
             (void)hipFree(spacer[k]);
-        if (cand[k] && k != chosen)
+        if (cand[k] && k != in && k != out)
             (void)hipFree(cand[k]);
     }
-    if (b->tune.place_debug)
-        fprintf(stderr, "cmhip place: output array = candidate %d (the frees took %.0f ms)\n", chosen,
-                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_free).count());
-    if (chosen != 0) {
-        b->d_out = (int16_t *)cand[chosen];
-        HIP_TRY(hipMemsetAsync(b->d_out, 0, bytes, b->stream));
-    }
-    // the probes ran the batch's kernel: whatever they left in the windows and the float planes goes
     if (!probed)
         return COOLMIC_ERROR_NONE;
+    // the probes ran the batch's kernel: whatever they left in the arrays, the windows and the float planes goes
+    b->d_in = (int16_t *)cand[in];
+    b->d_out = (int16_t *)cand[out];
+    HIP_TRY(hipMemsetAsync(b->d_in, 0, bytes, b->stream));
+    HIP_TRY(hipMemsetAsync(b->d_out, 0, bytes, b->stream));
     if (b->d.flags & CMHIP_VU)
         for (int i = 0; i < 3; i++)
             HIP_TRY(hipMemsetAsync(b->d_vu2[i], 0, b->d.streams * sizeof(VuState), b->stream));
@@ -549,9 +552,9 @@ static int batch_init(cmhip_batch_t *b)
             b->h_param[s].chmap[c] = (uint8_t)(c < d.channels ? c : 0);
         rebuild_param(b, (unsigned)s);
     }
-    // a separate PCM output array of its own: where it lies against the input array (place_output_apart)
+    // PCM arrays of its own, input and output apart: where they lie against each other (place_arrays_apart)
     if (b->d_out && b->d_out != b->d_in && !(d.flags & (CMHIP_HOSTPCM | CMHIP_EXTSLOTS | CMHIP_EQ))) {
-        if (flush_params(b) || place_output_apart(b, pcm_bytes))
+        if (flush_params(b) || place_arrays_apart(b, pcm_bytes))
             return COOLMIC_ERROR_GENERIC;
     }
     HIP_TRY(hipStreamSynchronize(b->stream));

@@ -948,7 +948,7 @@ hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hip
         // Waves per workgroup of the runs that write PCM and keep a window (see run_fast).  Over 36 pairs of
         // input and output arrays in one process, three boxes (tools/placement_forms.py): 1 wave 0.356-0.361 ms,
         // 2 0.348-0.357, 4 0.346-0.351, 8 0.344-0.349 on config 2 (no window: 0.327-0.332) -- but only the
-        // four-wave form also gains from arrays that lie apart (alloc_output_apart in cmhip_batch.hip:
+        // four-wave form also gains from arrays that lie apart (place_arrays_apart in cmhip_batch.hip:
         // 0.333 ms, against 0.345-0.354 for eight waves and 0.340-0.351 for one).  The read-only runs
         // (16 KiB tiles, a quarter of the atomics per byte) lose with more than one wave: 0.171 / 0.175 /
         // 0.181 / 0.207 ms for 1 / 2 / 4 / 8.
