@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -306,7 +307,7 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
 // of different kinds some are better than others).  Nothing but the virtual address is visible from
 // here, so the output array is chosen by probing: candidates 4 to 32 GiB apart (spacer allocations in
 // between, freed afterwards), the batch's own run into each, timed between two timings
-// of the first candidate; the fastest one is kept if it beats the first by more than 2.5 %.  Only for
+// of the first candidate; the fastest one is kept if it beats the first by more than 3 %.  Only for
 // arrays of 256 MiB and more, only while the card has the room and within 0.3 s, once per device and
 // process (place_search_allowed), off with CMHIP_PLACE=0.
 constexpr size_t PLACE_MIN_BYTES = 256ull << 20;
@@ -375,7 +376,7 @@ static int flush_params(cmhip_batch_t *b);
 
 // The batch has its two PCM arrays where hipMalloc first put them (candidates 0 and 1).  More candidates
 // follow behind spacers; every pair of candidates is a possible (input, output) -- nothing is in the arrays
-// yet -- and the pair the batch's own run is fastest on is kept if it beats the first by more than 2.5 %.
+// yet -- and the pair the batch's own run is fastest on is kept if it beats the first by more than 3 %.
 static int place_arrays_apart(cmhip_batch_t *b, size_t bytes)
 {
     bool probed = false;
@@ -406,21 +407,31 @@ static int place_arrays_apart(cmhip_batch_t *b, size_t bytes)
                 break;
         // (only the best kind of pair is worth taking: 3-7 % faster than a pair of one kind; differences of
         // 1-2 % between pairs do not last)
-        double best = 0.975;                              // time of a pair over that of the first
+        double refs[PLACE_TRIES + 1], tbest = 0.;
+        int nref = 0, bi = 0, bj = 1;
         for (int i = 0; i < n; i++) {
             const double ref = place_probe_ms(b, cand[0], cand[1], e0, e1);     // (again per row: clocks drift)
+            if (ref > 0.)
+                refs[nref++] = ref;
             for (int j = i + 1; j < n && ref > 0.; j++) {
                 if (i == 0 && j == 1)
                     continue;
                 const double t = place_probe_ms(b, cand[i], cand[j], e0, e1);
                 if (b->tune.place_debug)
                     fprintf(stderr, "cmhip place: %d -> %d: %.4f ms (0 -> 1: %.4f ms)\n", i, j, t, ref);
-                if (t > 0. && t < best * ref) {
-                    best = t / ref;
-                    in = i;
-                    out = j;
+                if (t > 0. && (tbest == 0. || t < tbest)) {
+                    tbest = t;
+                    bi = i;
+                    bj = j;
                 }
             }
+        }
+        // the first pair's time: the median of its samples (they scatter by 1-2 %); the fastest other pair is
+        // taken if it is 3 % faster than that
+        std::sort(refs, refs + nref);
+        if (nref && tbest > 0. && tbest < 0.97 * refs[nref / 2]) {
+            in = bi;
+            out = bj;
         }
         if (b->tune.place_debug)
             fprintf(stderr, "cmhip place: input = candidate %d, output = candidate %d, %.0f ms\n", in, out, 1e3 * elapsed());
