@@ -634,6 +634,38 @@ def test_full_size_config2_properties(gpu, oracle):
     v.close()
 
 
+@pytest.mark.parametrize("place", ["0", "2"])
+def test_arrays_placed_apart_hold_the_same_results(gpu, oracle, place, monkeypatch):
+    """A batch with PCM arrays of 256 MiB and more may move both of them at the end of its creation, to
+    where its own run is fastest (`place_arrays_apart`; $CMHIP_PLACE=2 makes every batch search,
+    0 none).  Whatever it chose, the probes leave nothing behind: uploads, the input read back, PCM and the
+    windows of the first launch against the oracle."""
+    cm = gpu
+    monkeypatch.setenv("CMHIP_PLACE", place)
+    S, C, T = 1024, 2, 65536                      # 256 MiB per array
+    b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU)
+    for s in (0, 511, 1023):                      # nothing in the windows, zeros in the arrays
+        assert b.vu_raw(s)[2] == 0
+        assert not b.download(s, 64).any()
+    gains, cmap = [750, 1250], [1, 0]
+    assert b.set_gain(-1, 2, 1000, gains) == 0 and b.set_chmap(-1, cmap) == 0
+    rng = np.random.default_rng(31)
+    xs = {s: _rand_pcm(rng, T * C, "full") for s in (0, 3, 1023)}
+    b.generate(cm.GEN_NOISE, 12345, T)
+    for s, x in xs.items():
+        b.upload(s, x)
+        assert np.array_equal(b.download_input(s, T), x), s
+    b.run(T)
+    res, rcs = b.vu_results()
+    for s in (0, 3, 7, 512, 1023):
+        src = xs[s] if s in xs else oracle.lcg(12345 + s, T * C)
+        want = _oracle_block(oracle, src, C, (2, 1000, gains), cmap)
+        assert np.array_equal(b.download(s, T), want), (place, s)
+        _, ro = _oracle_vu(oracle, [want], C)
+        assert rcs[s] == 0 and res[s].as_dict() == of.vu_result_dict(ro), (place, s)
+    b.close()
+
+
 def test_full_size_config4_total_on_one_gpu(gpu, oracle):
     """BASELINE configs 4/5 hold 65 536 mono streams; all of them on ONE GPU at 65 536 frames are
     8 GiB of PCM per array, so slot offsets pass 2^32 bytes (stream 32 768 starts at exactly 4 GiB).
