@@ -311,13 +311,13 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
 // arrays of 256 MiB and more, only while the card has the room and within 0.3 s, once per device and
 // process (place_search_allowed), off with CMHIP_PLACE=0.
 constexpr size_t PLACE_MIN_BYTES = 256ull << 20;
-// Spacers before candidates 1, 2, ...: 40 GiB in all reach past one whole stretch.  (Larger ones reach further
+// Spacers before candidates 2, 3, ...: 68 GiB in all reach past two whole stretches.  (Larger ones reach further
 // -- 4 ... 32 GiB, 124 in all, found the best kind of pair more often -- but allocating from memory that this or
 // an earlier process has freed is slow on this driver, which hands out cleared pages: single allocations of
 // 16-32 GiB were seen to take 3-6 s.)
-constexpr size_t PLACE_SPACER_GIB[] = {0, 4, 8, 12, 16};
-constexpr int PLACE_TRIES = 5;
-constexpr size_t PLACE_SPACER_SUM = (4ull + 8 + 12 + 16) << 30;
+constexpr size_t PLACE_SPACER_GIB[] = {0, 4, 8, 16, 16, 24};
+constexpr int PLACE_TRIES = 6;
+constexpr size_t PLACE_SPACER_SUM = (4ull + 8 + 16 + 16 + 24) << 30;
 constexpr double PLACE_BUDGET_S = 0.3;
 
 // a probe: the batch's own run (as created: no gain, no maps), full slots, from one candidate into another
@@ -354,7 +354,7 @@ static double place_probe_ms(cmhip_batch_t *b, const void *src, void *dst, hipEv
     return (double)ms / n;
 }
 
-// One search per device and process (CMHIP_PLACE=2: for every batch): the spacers are 40 GiB that go back to
+// One search per device and process (CMHIP_PLACE=2: for every batch): the spacers are 68 GiB that go back to
 // the driver, and allocating from memory the process has freed is slow on this driver (see PLACE_SPACER_GIB).
 static bool place_search_allowed(const cmhip_batch_t *b)
 {
