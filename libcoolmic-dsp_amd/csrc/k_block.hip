@@ -7,7 +7,9 @@
 //   * 16 bytes per lane per load/store (global_load_dwordx4), 1 KiB per wave
 //     instruction, four loads in flight per lane before the first use;
 //   * a wave owns a contiguous chunk of ONE stream, so stream parameters live in
-//     SGPRs and there is no barrier and no LDS traffic in the hot kernel;
+//     SGPRs and the waves share nothing while they work (the mono / stereo runs that write
+//     PCM and keep a window put four of them into a workgroup that merges their window
+//     sums in LDS at the very end: a quarter of the global atomics);
 //   * exact integer arithmetic only: 24-bit multiplies, one mul_hi for the division,
 //     64-bit integer atomics for the VU window (order independent => bit exact).
 //
@@ -930,7 +932,7 @@ hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hip
     if (a.streams == 0 || a.frames == 0)
         return hipSuccess;
     if (a.channels <= 2) {
-        // one 64-thread block per tile: 4 KiB when PCM or float is written, larger read-only
+        // one wave per tile: 4 KiB when PCM or float is written, larger read-only
         RunArgs b = a;
         u32 tile_u = TILE_U;
         if (!pcm && !f32) {
