@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random parity sweep of the EQ path against the oracle: 0..4 sections, 1..16 channels, maps,
 gains, ragged lengths, every output set, state and VU windows carried over several launches.
-Usage: python tools/fuzz_eq.py [cases] [seed]"""
+Usage: python tests/fuzz_eq.py [cases] [seed]"""
 import os
 import sys
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random parity sweep of the block kernels against the oracle (beyond the fixed seeds of tests/):
 channel counts 1..16, maps, gains, ragged lengths, every output set, windows over several launches.
-Usage: python tools/fuzz_parity.py [cases] [seed]"""
+Usage: python tests/fuzz_parity.py [cases] [seed]"""
 import os
 import sys
 

@@ -10,7 +10,6 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
-from oracle import oracle_ffi
 
 cm = ge.load_package()
 S, C, T = 4096, 2, 16384           # 256 MiB in + 256 MiB out per block
@@ -47,9 +46,5 @@ dt = time.perf_counter() - t0
 samples = S * C * T * steps
 print(f"PCIe-inclusive: {samples / dt / 1e6:.0f} Msamples/s  "
       f"({samples * 2 / dt / 1e9:.1f} GB/s each way, {dt / steps * 1e3:.2f} ms per {S}x{C}x{T} block)")
-# spot check stream 5 of the last block of buffer 1 against the oracle
-orc = oracle_ffi.Oracle()
-_, g = orc.gain(C, 2, 1000, [750, 1250])
-want = orc.gain_apply(g, orc.chmap([1, 0], hin[1].array[5, :T * C], C), C)
-assert np.array_equal(hout[1].array[5, :T * C], want)
-print("spot check ok")
+# (parity of this path: tests/test_gpu_parity.py::test_host_resident_slots and the upload_all / download_all
+# tests -- the oracle is the tests' checker, tools do not load it)
