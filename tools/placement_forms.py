@@ -39,9 +39,10 @@ def make(flags, env=None):
 
 
 RO = len(sys.argv) > 2 and sys.argv[2] == "ro"          # the read-only runs (VU only): no output array, no pairs
-forms = [("NW=%s" % n, make(cm.VU if RO else cm.OUT_PCM | cm.VU, ("CMHIP_FAST_NW", n))) for n in (("1", "4", "8") if Cn <= 2 else ("1",))]
+F32 = cm.OUT_F32 if os.environ.get("PF_F32") else 0            # float planes beside the PCM result
+forms = [("NW=%s" % n, make(cm.VU if RO else cm.OUT_PCM | cm.VU | F32, ("CMHIP_FAST_NW", n))) for n in (("1", "4", "8") if Cn <= 2 else ("1",))]
 if not RO:
-    forms.insert(1, ("no window", make(cm.OUT_PCM)))
+    forms.insert(1, ("no window", make(cm.OUT_PCM | F32)))
 for extra in sys.argv[3:]:                # other builds of the library (timing-only variants), on the same arrays
     import importlib.util
     os.environ["COOLMIC_HIP_LIB"] = os.path.abspath(extra)
