@@ -352,6 +352,18 @@ void k_eq_pipe(EqArgs a)
 #ifdef CMHIP_EQ_STAMPS
     u64 st_busy = 0, st_p[3] = {0, 0, 0};
     const u64 st_begin = __builtin_readcyclecounter();
+    // which wave reaches the barrier last (sampled every 16th step: the look itself delays wave 0's next
+    // step), and how long the first one waits for it.  One 256-byte block: the tiles in dynamic LDS behind
+    // it keep their 16-byte alignment.
+    struct alignas(256) StampLds { u32 arr[2][16]; u32 last[16]; unsigned long long skew; u32 pad[14]; };
+    static_assert(sizeof(StampLds) == 256, "");
+    __shared__ StampLds st_lds;
+    u32 st_n = 0;
+    if (threadIdx.x < 16)
+        st_lds.last[threadIdx.x] = 0;
+    if (threadIdx.x == 0)
+        st_lds.skew = 0;
+    __syncthreads();
 #endif
     // Schedule: F_k of block b is written in step b+2k, Y_k in step b+2k+1, the block leaves in
     // step b+2*NSEC.  Every buffer is read one step after it was written, so two slots do.
@@ -709,8 +721,24 @@ void k_eq_pipe(EqArgs a)
         const u64 st_t0 = __builtin_readcyclecounter();                 \
         call;                                                           \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
-        st_busy += __builtin_readcyclecounter() - st_t0;                \
+        const u64 st_t1 = __builtin_readcyclecounter();                 \
+        st_busy += st_t1 - st_t0;                                       \
+        if (lane == 0)                                                  \
+            st_lds.arr[st_n & 1u][wave] = (u32)st_t1;                   \
         __syncthreads();                                                \
+        if (threadIdx.x == 0 && (st_n & 15u) == 0) {                    \
+            const u32 nw_ = blockDim.x >> 6, ref_ = st_lds.arr[st_n & 1u][0]; \
+            int lo_ = 0, hi_ = 0;                                       \
+            u32 who_ = 0;                                               \
+            for (u32 w_ = 1; w_ < nw_; w_++) {                          \
+                const int d_ = (int)(st_lds.arr[st_n & 1u][w_] - ref_); \
+                if (d_ > hi_) { hi_ = d_; who_ = w_; }                  \
+                if (d_ < lo_) lo_ = d_;                                 \
+            }                                                           \
+            st_lds.last[who_]++;                                        \
+            st_lds.skew += (unsigned long long)(hi_ - lo_);             \
+        }                                                               \
+        st_n++;                                                         \
     } while (0)
 #else
 #define EQ_STEP(call) do { call; __syncthreads(); } while (0)
@@ -786,6 +814,12 @@ void k_eq_pipe(EqArgs a)
                 a.dbg[50 + 3 * tw + i] = st_p[i];
         }
         a.dbg[24 + wave] = role;
+    }
+    __syncthreads();
+    if (blockIdx.x == 7 && threadIdx.x == 0 && a.dbg) {
+        for (u32 w_ = 0; w_ < 12; w_ += 2)
+            a.dbg[56 + w_ / 2] = (u64)st_lds.last[w_] | ((u64)st_lds.last[w_ + 1] << 32);
+        a.dbg[62] = st_lds.skew;
     }
 #endif
 

@@ -14,7 +14,7 @@ b = cm.Batch(S, 1, T, flags=cm.EQ | cm.OUT_F32)
 b.set_eq(-1, cm.eq3())
 b.set_gain(-1, 1, 1000, [900])
 b.generate(cm.GEN_NOISE, 12345, T)
-for _ in range(2):
+for _ in range(int(os.environ.get("EQ_STAMP_RUNS", "60"))):      # (sustained clocks; the stamps are the last launch's)
     b.run(T)
 b.sync()
 out = (C.c_uint64 * 64)()
@@ -32,3 +32,10 @@ for i in range(2):
     p = [out[50 + 3 * i + j] / nsteps for j in range(3)]
     if any(p):
         print(f"T wave {i}: PCM arrived at {p[0]:7.1f}, converted at {p[1]:7.1f}, F_0 queued at {p[2]:7.1f} clk into the step")
+last = []
+for w in range(12):
+    word = out[56 + w // 2]
+    last.append((word >> (32 * (w & 1))) & 0xffffffff)
+if sum(last):
+    print("last at the barrier, share of the steps: " + "  ".join("w%d %.0f%%" % (w, 100.0 * c / sum(last)) for w, c in enumerate(last) if c))
+    print("first to last arrival at the barrier: %.0f clk per step on average" % (out[62] / max(sum(last), 1)))
