@@ -82,11 +82,26 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def under_profiler():
+    """rocprofv3 preloads its tool library (LD_PRELOAD = ...librocprofiler-sdk-tool.so:librocprofiler-sdk.so,
+    ROCP_TOOL_LIBRARIES names it), which initialises the GPU before main() runs: starting rank processes
+    from such a process is an exec from one that holds the GPU."""
+    return "librocprofiler-sdk" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))
+
+
 def launch_ranks(n):
     """The parent of a self-launched multi-GPU run: N fresh rank processes of this script, one
     per GPU, started before this process has loaded the engine or touched HIP (nothing is
     exec'ed from a process that initialised the GPU).  Relays rank 0's JSON line; returns the
-    worst exit code."""
+    worst exit code.  The whole launch has a wall-clock deadline ($COOLMIC_BENCH_DEADLINE_S,
+    default 900): ranks that are all alive but stuck -- a collective one of them never issued, a
+    hung GPU -- are ended (exactly the processes started here) and named, instead of leaving the
+    one command the driver runs without a line until gloo's half-hour timeout."""
+    if under_profiler():
+        sys.stderr.write("bench.py: --gpus %d under a profiler preload (rocprofv3): the profiler's library has "
+                         "initialised the GPU in this process, so it must not start the rank processes.  Profile "
+                         "one rank directly: RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 rocprofv3 ... -- python3 bench.py\n" % n)
+        return 2
     env0 = dict(os.environ)
     env0.setdefault("MASTER_ADDR", "127.0.0.1")
     env0.setdefault("MASTER_PORT", str(_free_port()))
@@ -108,6 +123,8 @@ def launch_ranks(n):
     reader = threading.Thread(target=drain, daemon=True)
     reader.start()
     worst = 0
+    t_start = time.time()
+    overall = t_start + float(os.environ.get("COOLMIC_BENCH_DEADLINE_S", "900"))
     deadline = None
     pending = list(procs)
     while pending:
@@ -120,10 +137,18 @@ def launch_ranks(n):
                 worst = worst or rc
                 if deadline is None:            # a rank died: the others would wait at a barrier for ever
                     deadline = time.time() + 20.0
-        if deadline is not None and time.time() > deadline:
+        now = time.time()
+        if pending and now > overall:
+            alive = [procs.index(p) for p in pending]
+            sys.stderr.write("bench.py: deadline of %.0f s passed with rank(s) %s still running (stuck at a "
+                             "collective or a hung GPU?); ending them\n" % (now - t_start, alive))
+            worst = worst or 124
+            deadline = now - 1.0
+            overall = now + 1e9
+        if deadline is not None and now > deadline:
             for p in pending:
                 p.kill()                        # exactly the processes started above
-            deadline = time.time() + 1e9
+            deadline = now + 1e9
         time.sleep(0.05)
     reader.join(timeout=10)
     line = lines[-1] if lines else b""
@@ -135,14 +160,24 @@ def launch_ranks(n):
     return worst
 
 
+def job_token():
+    """what tells this job's ranks from another job's on the same host"""
+    import hashlib
+    key = ":".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "TORCHELASTIC_RUN_ID"))
+    return hashlib.sha256(key.encode()).digest()[:16]
+
+
 def exchange_node_id(rank, world, make_id):
     """Config 5: rank 0's 128-byte RCCL id reaches the other ranks over a plain TCP socket next
     to MASTER_PORT -- before torch is imported, so that the engine and librccl both sit on the
-    system HIP runtime (torch, imported later for gloo only, brings a second one)."""
+    system HIP runtime (torch, imported later for gloo only, brings a second one).  A client says
+    who it is (magic, job token, rank); the server answers valid requests only and counts distinct
+    ranks, so a stray connection or another job's rank takes nobody's place."""
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     base = int(os.environ.get("MASTER_PORT", "29599"))
     ports = [base + 101 + 37 * i for i in range(8)]
     magic = b"cmhip-node-id:"
+    token = job_token()
     if world == 1:
         return make_id()
     if rank == 0:
@@ -156,33 +191,79 @@ def exchange_node_id(rank, world, make_id):
                 continue
         if srv is None:
             raise SystemExit("bench.py: no free port for the node id exchange near MASTER_PORT")
-        srv.settimeout(120)
-        served = 0
-        while served < world - 1:
-            conn, _ = srv.accept()
+        t_end = time.time() + 120
+        served = set()
+        want = len(magic) + len(token) + 4
+        while len(served) < world - 1:
+            srv.settimeout(max(0.1, t_end - time.time()))
+            try:
+                conn, _ = srv.accept()
+            except (socket.timeout, TimeoutError):
+                raise SystemExit("bench.py: node id exchange: only rank(s) %s of %d asked for the id within 120 s"
+                                 % (sorted(served), world))
             with conn:
-                conn.sendall(magic + uid)
-            served += 1
+                conn.settimeout(5)
+                try:
+                    req = b""
+                    while len(req) < want:
+                        chunk = conn.recv(want - len(req))
+                        if not chunk:
+                            break
+                        req += chunk
+                    peer = int.from_bytes(req[-4:], "little") if len(req) == want else -1
+                    if req.startswith(magic + token) and 0 < peer < world:
+                        conn.sendall(magic + token + uid)
+                        served.add(peer)
+                except OSError:
+                    pass                          # whoever that was, it was not one of ours
         srv.close()
         return uid
-    want = len(magic) + 128
+    hello = magic + token + rank.to_bytes(4, "little")
+    want = len(magic) + len(token) + 128
     t_end = time.time() + 120
     while time.time() < t_end:
         for p in ports:
             try:
                 with socket.create_connection((addr, p), timeout=2) as c:
+                    c.sendall(hello)
                     buf = b""
                     while len(buf) < want:
                         chunk = c.recv(want - len(buf))
                         if not chunk:
                             break
                         buf += chunk
-                if len(buf) == want and buf.startswith(magic):
-                    return buf[len(magic):]
+                if len(buf) == want and buf.startswith(magic + token):
+                    return buf[len(magic) + len(token):]
             except OSError:
                 continue
         time.sleep(0.1)
     raise SystemExit("bench.py: rank %d never received the node id" % rank)
+
+
+def warm_up(run_steps, steps, chunk, more):
+    """the steps asked for, then on in chunks while more() says so.  With several ranks more() is ONE
+    decision for all of them (rank 0's clock, broadcast): every rank runs the same number of steps, so
+    ranks that issue collectives in their steps (config 5) issue the same number of them."""
+    run_steps(steps)
+    done = steps
+    while more():
+        run_steps(chunk)
+        done += chunk
+    return done
+
+
+def collective_more(dist, rank, world, t_start, min_s):
+    """-> more(): has MIN_WARMUP_S of wall time passed?  One rank: its own clock.  Several: rank 0's,
+    broadcast over gloo, so that all ranks leave the warm-up loop after the same chunk."""
+    if world == 1:
+        return lambda: time.perf_counter() - t_start < min_s
+    import torch
+
+    def more():
+        flag = torch.tensor([1 if (rank == 0 and time.perf_counter() - t_start < min_s) else 0], dtype=torch.int32)
+        dist.broadcast(flag, src=0)
+        return bool(flag.item())
+    return more
 
 
 def main():
@@ -243,19 +324,51 @@ def main():
         flags = cm.EQ | cm.OUT_F32
     else:
         flags = cm.OUT_PCM | cm.VU
-    b = cm.Batch(S, Cn, T, flags=flags, device=local_rank)
-    if args.workload == "c2":
-        assert b.set_gain(-1, 2, 1000, [750, 1250]) == 0
-        assert b.set_chmap(-1, [1, 0]) == 0
-    elif os.environ.get("COOLMIC_BENCH_GAIN", "1") != "0":
-        assert b.set_gain(-1, 1, 1000, [900]) == 0
-    if eq:
-        assert b.set_eq(-1, cm.eq3(48000.0)) == 0
-    # global stream id of local stream s is rank + s*world (round-robin sharding)
+
+    def make_batch(extra_flags=0):
+        bb = cm.Batch(S, Cn, T, flags=flags | extra_flags, device=local_rank)
+        if args.workload == "c2":
+            assert bb.set_gain(-1, 2, 1000, [750, 1250]) == 0
+            assert bb.set_chmap(-1, [1, 0]) == 0
+        elif os.environ.get("COOLMIC_BENCH_GAIN", "1") != "0":
+            assert bb.set_gain(-1, 1, 1000, [900]) == 0
+        if eq:
+            assert bb.set_eq(-1, cm.eq3(48000.0)) == 0
+        # global stream id of local stream s is rank + s*world (round-robin sharding)
+        bb.generate(cm.GEN_NOISE, 12345, T, first_global=first_global, global_step=global_step)
+        bb.sync()
+        return bb
+
     n_local, first_global, global_step = shard.shard(S * world, world, rank)
     assert n_local == S
-    b.generate(cm.GEN_NOISE, 12345, T, first_global=first_global, global_step=global_step)
-    b.sync()
+
+    # Placement of the two PCM arrays: the LIBRARY's default is two plain allocations; this
+    # benchmark opts in to the engine's placement search (CMHIP_PLACE_SEARCH) and says so in the line --
+    # together with what the same workload's kernel takes in this process WITHOUT it: a batch made the
+    # default way first (the process's first two large allocations), timed, freed.
+    place_search = not eq and os.environ.get("COOLMIC_BENCH_PLACE", "1") != "0"
+    setup = {"placement_search": "on (bench.py passes CMHIP_PLACE_SEARCH; the library's default is off)"
+             if place_search else "off"}
+    if place_search:
+        t_c = time.perf_counter()
+        a0 = make_batch()
+        setup["batch_create_ms_place_off"] = round((time.perf_counter() - t_c) * 1e3, 1)
+        t_w0 = time.perf_counter()
+        while time.perf_counter() - t_w0 < MIN_WARMUP_S:
+            for _ in range(16):
+                a0.run(T)
+            a0.sync()
+        a0.timing(True)
+        a0.timing_read()
+        for _ in range(64):
+            a0.run(T)
+        ms0, n0 = a0.timing_read()
+        setup["kernel_avg_ms_place_off"] = round(ms0 / max(n0, 1), 4)
+        a0.close()
+    t_c = time.perf_counter()
+    b = make_batch(cm.PLACE_SEARCH if place_search else 0)
+    setup["batch_create_ms"] = round((time.perf_counter() - t_c) * 1e3, 1)
+    setup["placement"] = b.placement()
 
     # (the batch's PCM arrays are allocated before RCCL takes its buffers: the same order of
     # allocations as in the workloads without an exchange)
@@ -335,14 +448,12 @@ def main():
         b.sync()
 
     # warm-up: the steps asked for, then on until MIN_WARMUP_S of wall time have passed, so that a
-    # short run (the driver's --steps 20 --warmup 5) is timed at the clocks the chip then holds
+    # short run (the driver's --steps 20 --warmup 5) is timed at the clocks the chip then holds.  How
+    # many chunks that takes is decided once for all ranks (collective_more): with a data-path
+    # collective in the steps (config 5) every rank must issue the same number of them.
     t_w = time.perf_counter()
-    run_steps(args.warmup)
-    warm_steps = args.warmup
     chunk = max(8, NB if node_on else 8)
-    while time.perf_counter() - t_w < MIN_WARMUP_S:
-        run_steps(chunk)
-        warm_steps += chunk
+    warm_steps = warm_up(run_steps, args.warmup, chunk, collective_more(dist, rank, world, t_w, MIN_WARMUP_S))
     device_sync()
     warm_ms = (time.perf_counter() - t_w) * 1e3
 
@@ -419,6 +530,10 @@ def main():
     }
     if rehearsal:
         out["rehearsal"] = "all %d ranks share GPU 0 (COOLMIC_BENCH_REHEARSAL=1): not a scaling number" % world
+    out["setup"] = setup
+    if "kernel_avg_ms_place_off" in setup:
+        out["kernel_avg_ms_place_off"] = setup["kernel_avg_ms_place_off"]
+        out["config"]["workload"] += " [PCM arrays placed by the engine's search, CMHIP_PLACE_SEARCH: see setup]"
 
     if node_on and node_last[0] is not None:
         # the last exchanged set, decoded (outside the timed region)
@@ -484,6 +599,16 @@ def main():
             sweep["error"] = str(e)
         out["small_blocks_kernel_only"] = sweep
     b.close()
+
+    # Several ranks: configs 4 and 5 at this N, outside the timed region and never part of `value` -- the
+    # driver's one command passes no --workload, and config 5's exchange is the only collective of the path.
+    if world > 1:
+        try:
+            out["node_vu"] = node_vu_legs(cm, shard, dist, rank, world, local_rank, rehearsal, NB)
+        except SystemExit:
+            raise
+        except Exception as e:                 # (every rank fails alike or the deadline of launch_ranks ends the run)
+            out["node_vu"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     def kernel_only(batch, frames, warm=100, timed=100):
         for _ in range(warm):
@@ -567,25 +692,143 @@ def main():
     os.close(json_fd)
 
 
+NODE_LEG_SHAPE = (8192, 1, 65536)      # configs 4 / 5 per GPU: 65 536 mono streams round-robin over 8 GPUs
+NODE_VU_KEYS = ("rccl_ranks", "steps", "blocks_per_exchange", "shape_per_gpu", "ms_per_step_c4", "ms_per_step_c5",
+                "Msamples_s_c4", "Msamples_s_c5", "matches_host_merge", "check")
+
+
+def node_vu_legs(cm, shard, dist, rank, world, local_rank, rehearsal, NB, steps=None, warm=None):
+    """Configs 4 and 5 on all ranks of this run, one batch of the config-4 shape per rank:
+    leg c4 -- launch, window snapshot, host dB finish per step, no exchange; leg c5 -- the same plus the
+    block's node record and, per NB blocks, ONE pair of RCCL all-reduces over the records
+    (cmhip_node_allreduce).  Every rank runs the same fixed number of steps, so every rank issues the same
+    number of collectives.  Then the parity check of the RCCL path: the combined record of the last block
+    against cmhip_node_merge_host() of the ranks' un-reduced records of that block, gathered over gloo
+    (the "replicas only" form of SURVEY 8e)."""
+    import numpy as np
+    import torch
+    S, Cn, T = NODE_LEG_SHAPE
+    if os.environ.get("COOLMIC_BENCH_NODE_SHAPE"):           # (tests on small boxes)
+        S, Cn, T = (int(v) for v in os.environ["COOLMIC_BENCH_NODE_SHAPE"].split(","))
+    steps = steps or max(64, int(os.environ.get("COOLMIC_BENCH_NODE_STEPS", "128")))
+    steps -= steps % NB                                      # whole sets: the last block's set is full
+    warm = warm if warm is not None else 4 * NB
+    n_local, first_global, global_step = shard.shard(S * world, world, rank)
+    b = cm.Batch(S, Cn, T, flags=cm.OUT_PCM | cm.VU, device=local_rank)
+    assert b.set_gain(-1, 1, 1000, [900]) == 0
+    b.generate(cm.GEN_NOISE, 12345, T, first_global=first_global, global_step=global_step)
+    b.sync()
+    if rehearsal:
+        node = cm.Node(local_rank, 1, 0, cm.node_unique_id(), max_records=NB)
+    else:
+        # (the id travels over gloo here: torch is loaded by now, and librccl was resolved -- next to the
+        # HIP runtime the engine runs on -- before that, when the engine made the id)
+        uid = torch.zeros(cm.NODE_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.tensor(list(cm.node_unique_id()), dtype=torch.uint8)
+        dist.broadcast(uid, src=0)
+        node = cm.Node(local_rank, world, rank, bytes(uid.tolist()), max_records=NB)
+    results = (cm.VuResult * S)()
+    rcs = (C.c_int * S)()
+    own = [None]                                 # this rank's un-reduced record of the last block
+
+    def sync_all():
+        cm.device_synchronize(local_rank)
+        dist.barrier()
+        cm.device_synchronize(local_rank)
+
+    def run(n, with_node, keep_last=False):
+        pending = False
+        for i in range(n):
+            b.run(T)
+            if with_node:
+                k, slot = (i // NB) & 1, i % NB
+                if keep_last and i == n - 1:
+                    own[0] = b.node_record(first_global=first_global, global_step=global_step)
+                node.partial(b, k, slot, first_global=first_global, global_step=global_step)
+                if slot == NB - 1:
+                    node.allreduce(k, NB, after=b)
+            b.vu_snapshot()
+            if pending:
+                b.vu_collect(results, rcs)
+            pending = True
+        if pending:
+            b.vu_collect(results, rcs)
+        b.sync()
+
+    def timed(with_node, keep_last=False):
+        run(warm, with_node)
+        sync_all()
+        t0 = time.perf_counter()
+        run(steps, with_node, keep_last)
+        sync_all()
+        return shard.max_over_ranks(dist, time.perf_counter() - t0, device="cpu") / steps * 1e3
+
+    ms_c4 = timed(False)
+    ms_c5 = timed(True, keep_last=True)
+    k_last = ((steps - 1) // NB) & 1
+    combined = node.fetch(k_last, NB)[NB - 1]
+    mine = torch.from_numpy(own[0].copy())
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    records = np.stack([p.numpy() for p in parts])
+    merged = cm.node_merge_host(records)
+    # what the communicator's ranks should have produced together (rehearsal: one-rank communicators)
+    expect = cm.node_merge_host(records[rank:rank + 1]) if rehearsal else merged
+    ok = torch.tensor([1 if np.array_equal(expect, combined) else 0], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    rc, r = cm.node_finish(merged, Cn)
+    out = {"rccl_ranks": node.ranks(), "steps": steps, "blocks_per_exchange": NB,
+           "shape_per_gpu": "%d x %d ch x %d frames, gain 900/1000, PCM + VU" % (S, Cn, T),
+           "ms_per_step_c4": round(ms_c4, 4), "ms_per_step_c5": round(ms_c5, 4),
+           "Msamples_s_c4": round(S * Cn * T * world / (ms_c4 * 1e-3) / 1e6, 1),
+           "Msamples_s_c5": round(S * Cn * T * world / (ms_c5 * 1e-3) / 1e6, 1),
+           "matches_host_merge": bool(ok.item()),
+           "check": "RCCL-combined record of the last block == cmhip_node_merge_host of the %s un-reduced "
+                    "records gathered over gloo, on every rank" % ("rank's own" if rehearsal else "ranks'")}
+    assert set(NODE_VU_KEYS) <= set(out)
+    if rehearsal:
+        out["rehearsal"] = "one-rank communicators (RCCL refuses two ranks on one GPU): rccl_ranks is 1"
+    if rc == 0:
+        out["last_block"] = {"frames": r.frames, "global_peak": r.global_peak, "global_power_db": r.global_power}
+    node.close()
+    b.close()
+    return out
+
+
 def dry_run(args, rank, world, json_fd, shard):
     if os.environ.get("COOLMIC_BENCH_DRYRUN_FAIL_RANK") == str(rank):      # (test hook: a rank that dies early)
         sys.exit(3)
+    if os.environ.get("COOLMIC_BENCH_DRYRUN_HANG_RANK") == str(rank):      # (test hook: a rank that never gets there)
+        time.sleep(3600)
     uid = exchange_node_id(rank, world, lambda: os.urandom(128)) if args.workload == "c5" else b""
     out = {"metric": "Msamples/s transform->vumeter", "value": 0.0, "unit": "Msamples/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "dry_run": True,
            "config": {"workload": args.workload}}
+    dist = None
     if world > 1:
         import torch
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dist.barrier()
+    # the warm-up loop of the real run with steps that take rank-dependent time: left to its own clock every
+    # rank would stop after a different chunk; the decision is rank 0's, so the counts are equal
+    t_w = time.perf_counter()
+    warm_steps = warm_up(lambda n: time.sleep(n * 0.002 * (1 + 2 * rank)), args.warmup, 8,
+                         collective_more(dist, rank, world, t_w, MIN_WARMUP_S))
+    out["warmup_steps_effective"] = warm_steps
+    if world > 1:
         out["clock_max_over_ranks"] = shard.max_over_ranks(dist, 1.0 + rank, device="cpu")
         ids = [torch.zeros(128, dtype=torch.uint8) for _ in range(world)]
         dist.all_gather(ids, torch.tensor(list(uid.ljust(128, b"\0")), dtype=torch.uint8))
         out["node_id_same_on_all_ranks"] = all(bool((i == ids[0]).all()) for i in ids)
-        ranks = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(ranks, torch.tensor([rank]))
-        out["ranks_seen"] = [int(r.item()) for r in ranks]
+        ranks = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(ranks, torch.tensor([rank, warm_steps]))
+        out["ranks_seen"] = [int(r[0].item()) for r in ranks]
+        out["warmup_steps_all_ranks"] = [int(r[1].item()) for r in ranks]
+        # the keys the real run's config-4 / config-5 legs report (node_vu_legs), no GPU work behind them here
+        out["node_vu"] = dict.fromkeys(NODE_VU_KEYS)
+        out["node_vu"]["rccl_ranks"] = 0
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

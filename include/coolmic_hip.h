@@ -44,6 +44,9 @@ typedef struct cmhip_batch cmhip_batch_t;
 #define CMHIP_HOSTPCM      0x0020u   /* PCM slots in pinned host memory the kernels access directly (zero copy):
                                       * for small batches fed block by block, e.g. the per-stream stages */
 #define CMHIP_EXTSLOTS     0x0040u   /* no PCM slots of its own: every run names them (cmhip_batch_run_slots) */
+#define CMHIP_PLACE_SEARCH 0x0080u   /* at creation, look for a faster physical placement of the two PCM arrays
+                                      * (cmhip_batch_placement below).  OFF unless asked for: the search takes
+                                      * memory and time for a few per cent of the kernel */
 
 /* synthetic inputs generated on the device */
 #define CMHIP_GEN_NULL     0         /* zeros, as snddev "null" */
@@ -65,12 +68,42 @@ typedef struct cmhip_batch_desc {
 /* ---- process level ------------------------------------------------------- */
 int          cmhip_device_count(void);            /* 0 without a usable GPU */
 int          cmhip_device_synchronize(int device); /* everything queued on that device has finished */
+int          cmhip_device_mem_info(int device, size_t *free_bytes, size_t *total_bytes); /* hipMemGetInfo */
+/* plain device memory for a host without HIP headers of its own (e.g. the destination of
+ * cmhip_batch_vu_node_partial for a host that brings its own collective); zero-filled */
+void        *cmhip_device_alloc(int device, size_t bytes);        /* NULL on failure */
+void         cmhip_device_free(int device, void *p);
+int          cmhip_device_read(int device, void *dst_host, const void *src_device, size_t bytes); /* synchronises the device */
 const char  *cmhip_last_error(void);              /* per-thread text of the last failure */
 const char  *cmhip_version(void);
 
 /* ---- life cycle ---------------------------------------------------------- */
 cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc);   /* NULL on failure */
 void           cmhip_batch_free(cmhip_batch_t *b);
+
+/* ---- placement of the PCM arrays (CMHIP_PLACE_SEARCH) ---------------------- */
+/* On MI355X a kernel that streams one large array in and another out runs 3-5 % faster when the two
+ * lie in different stretches of the card's memory; nothing but probing shows which.  A batch created
+ * with CMHIP_PLACE_SEARCH (two PCM arrays of its own, >= 256 MiB each) allocates up to five more
+ * candidate arrays behind spacer allocations, times its own run on every pair, keeps the fastest pair
+ * if it beats the first by 2 % and frees the rest before cmhip_batch_new() returns.  It never asks
+ * for more than HALF of the memory hipMemGetInfo reports free (spacers and candidates together;
+ * fewer candidates on a fuller card) and stops allocating after 0.3 s.  Without the flag nothing of
+ * this happens: two hipMalloc calls, no probe launches.  $CMHIP_PLACE overrides for experiments:
+ * 0 never, 1 the first large batch of a device even without the flag, 2 every large batch. */
+typedef struct cmhip_placement {
+    int      searched;          /* 1 when the probes ran */
+    int      candidates;        /* arrays probed, the first two included (2..7) */
+    int      chosen_in;         /* candidate kept as the input array (0 = where hipMalloc first put it) */
+    int      chosen_out;        /* candidate kept as the output array (1 = where hipMalloc first put it) */
+    int      probe_launches;    /* launches of the batch's kernel the search made */
+    double   first_pair_ms;     /* the run on the first pair (median of its probes; no gain, no map) */
+    double   best_pair_ms;      /* the run on the fastest other pair */
+    double   search_ms;         /* wall time of the whole search */
+    uint64_t bytes_requested;   /* spacers + extra candidates the search allocated (all freed again) */
+    uint64_t bytes_free_before; /* hipMemGetInfo free when it started */
+} cmhip_placement_t;
+int cmhip_batch_placement(const cmhip_batch_t *b, cmhip_placement_t *out);
 
 /* ---- parameters (take effect at the next run) ---------------------------- */
 /* same meaning and return values as coolmic_transform_set_master_gain
@@ -162,6 +195,9 @@ int cmhip_batch_vu_raw(cmhip_batch_t *b, unsigned int stream, int64_t *power, in
 #define CMHIP_NODE_SUM_WORDS  17
 int cmhip_batch_vu_node_partial(cmhip_batch_t *b, void *dst_device, uint64_t first_global,
                                 uint64_t global_step);
+/* the same record straight to host memory, words[CMHIP_NODE_WORDS]; waits for the batch's last run */
+int cmhip_batch_vu_node_record(cmhip_batch_t *b, int64_t *words_host, uint64_t first_global,
+                               uint64_t global_step);
 /* host: turn a combined record into a result (frames = total frames over streams) */
 int cmhip_node_finish(const int64_t *words, unsigned int channels, unsigned int rate,
                       coolmic_vumeter_result_t *out);
@@ -187,6 +223,9 @@ cmhip_node_t *cmhip_node_new(int device, int nranks, int rank, const void *id128
                              unsigned int max_records);
 void          cmhip_node_free(cmhip_node_t *n);
 int           cmhip_node_ranks(const cmhip_node_t *n);
+/* "hip=<path of the HIP runtime the engine is bound to> rccl=<path of the librccl it loaded>": librccl is
+ * taken from next to that runtime (a process that also imported a torch wheel holds a second pair) */
+const char   *cmhip_node_runtime(void);
 /* the batch's current windows -> slot `slot` of set `set` (asynchronous, beside the batch's
  * next run; the batch must live on the node's device).  Waits, on the device, for the last
  * exchange of that set, and clears the set when its first slot after an exchange is filled:

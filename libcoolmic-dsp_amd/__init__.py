@@ -30,6 +30,7 @@ ERROR_NONE, ERROR_GENERIC, ERROR_NOSYS, ERROR_FAULT = 0, -1, -8, -9
 ERROR_INVAL, ERROR_NOMEM, ERROR_BUSY = -10, -11, -12
 
 OUT_PCM, OUT_F32, VU, INPLACE, EQ, HOSTPCM, EXTSLOTS = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40
+PLACE_SEARCH = 0x80
 GEN_NULL, GEN_SINE, GEN_NOISE = 0, 1, 2
 NODE_WORDS = 34
 
@@ -59,6 +60,22 @@ class BatchDesc(C.Structure):
                 ("hip_stream", C.c_void_p)]
 
 
+class Placement(C.Structure):
+    """cmhip_placement_t (include/coolmic_hip.h)"""
+    _fields_ = [("searched", C.c_int), ("candidates", C.c_int), ("chosen_in", C.c_int),
+                ("chosen_out", C.c_int), ("probe_launches", C.c_int), ("first_pair_ms", C.c_double),
+                ("best_pair_ms", C.c_double), ("search_ms", C.c_double),
+                ("bytes_requested", C.c_uint64), ("bytes_free_before", C.c_uint64)]
+
+    def as_dict(self):
+        return {"searched": bool(self.searched), "candidates": self.candidates,
+                "chosen": [self.chosen_in, self.chosen_out], "probe_launches": self.probe_launches,
+                "first_pair_ms": round(self.first_pair_ms, 4), "best_pair_ms": round(self.best_pair_ms, 4),
+                "search_ms": round(self.search_ms, 1),
+                "GiB_requested": round(self.bytes_requested / 2**30, 2),
+                "GiB_free_before": round(self.bytes_free_before / 2**30, 2)}
+
+
 def _sig(name, res, args):
     fn = getattr(lib, name)
     fn.restype = res
@@ -73,10 +90,15 @@ SIGNATURES = {
     # include/coolmic_hip.h
     "cmhip_device_count": (C.c_int, []),
     "cmhip_device_synchronize": (C.c_int, [C.c_int]),
+    "cmhip_device_mem_info": (C.c_int, [C.c_int, _P(C.c_size_t), _P(C.c_size_t)]),
+    "cmhip_device_alloc": (_vp, [C.c_int, C.c_size_t]),
+    "cmhip_device_free": (None, [C.c_int, _vp]),
+    "cmhip_device_read": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t]),
     "cmhip_last_error": (C.c_char_p, []),
     "cmhip_version": (C.c_char_p, []),
     "cmhip_batch_new": (_vp, [_P(BatchDesc)]),
     "cmhip_batch_free": (None, [_vp]),
+    "cmhip_batch_placement": (C.c_int, [_vp, _P(Placement)]),
     "cmhip_batch_set_gain": (C.c_int, [_vp, C.c_long, C.c_uint, C.c_uint16, _P(C.c_uint16)]),
     "cmhip_batch_set_chmap": (C.c_int, [_vp, C.c_long, _vp]),
     "cmhip_batch_set_eq": (C.c_int, [_vp, C.c_long, C.c_uint, _vp]),
@@ -107,6 +129,7 @@ SIGNATURES = {
     "cmhip_batch_vu_reset": (C.c_int, [_vp, C.c_long]),
     "cmhip_batch_vu_raw": (C.c_int, [_vp, C.c_uint, _vp, _vp, _P(C.c_uint64)]),
     "cmhip_batch_vu_node_partial": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64]),
+    "cmhip_batch_vu_node_record": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64]),
     "cmhip_node_finish": (C.c_int, [_vp, C.c_uint, C.c_uint, _P(VuResult)]),
     "cmhip_batch_run_slots": (C.c_int, [_vp, C.c_size_t, _vp, _vp, _vp]),
     "cmhip_host_alloc_mapped": (_vp, [C.c_size_t, _P(_vp)]),
@@ -114,6 +137,7 @@ SIGNATURES = {
     "cmhip_node_new": (_vp, [C.c_int, C.c_int, C.c_int, _vp, C.c_uint]),
     "cmhip_node_free": (None, [_vp]),
     "cmhip_node_ranks": (C.c_int, [_vp]),
+    "cmhip_node_runtime": (C.c_char_p, []),
     "cmhip_node_partial": (C.c_int, [_vp, _vp, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64]),
     "cmhip_node_allreduce": (C.c_int, [_vp, C.c_uint, C.c_uint, _vp]),
     "cmhip_node_fetch": (C.c_int, [_vp, C.c_uint, C.c_uint, _vp]),
@@ -209,6 +233,12 @@ def device_synchronize(device=0):
     _check("device_synchronize", lib.cmhip_device_synchronize(device))
 
 
+def device_mem_info(device=0):
+    f, t = C.c_size_t(), C.c_size_t()
+    _check("device_mem_info", lib.cmhip_device_mem_info(device, C.byref(f), C.byref(t)))
+    return f.value, t.value
+
+
 def last_error():
     return lib.cmhip_last_error().decode()
 
@@ -263,6 +293,12 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+    def placement(self):
+        """what the placement search of CMHIP_PLACE_SEARCH did at creation (a dict)"""
+        p = Placement()
+        _check("placement", lib.cmhip_batch_placement(self.h, C.byref(p)))
+        return p.as_dict()
 
     # parameters
     def set_gain(self, stream, channels, scale, gains):
@@ -373,6 +409,12 @@ class Batch:
         _check("node_partial", lib.cmhip_batch_vu_node_partial(self.h, dst_device_ptr, first_global,
                                                                global_step))
 
+    def node_record(self, first_global=0, global_step=1):
+        """this batch's un-reduced node record in host memory (waits for the last run)"""
+        out = np.zeros(NODE_WORDS, dtype=np.int64)
+        _check("node_record", lib.cmhip_batch_vu_node_record(self.h, out.ctypes.data, first_global, global_step))
+        return out
+
     # measurement
     def timing(self, enable):
         """True / 1: every run carries events; n > 1: every n-th run; False / 0: off"""
@@ -418,6 +460,26 @@ class PinnedPcm:
             self.ptr = None
 
 
+class DeviceWords:
+    """n int64 words of plain device memory (cmhip_device_alloc): `.dev` for the engine, read() for the host"""
+
+    def __init__(self, n, device=0):
+        self.n, self.device = n, device
+        self.dev = lib.cmhip_device_alloc(device, n * 8)
+        if not self.dev:
+            raise CoolmicError("cmhip_device_alloc", ERROR_NOMEM)
+
+    def read(self):
+        out = np.zeros(self.n, dtype=np.int64)
+        _check("device_read", lib.cmhip_device_read(self.device, out.ctypes.data, self.dev, self.n * 8))
+        return out
+
+    def free(self):
+        if self.dev:
+            lib.cmhip_device_free(self.device, self.dev)
+            self.dev = None
+
+
 class MappedPcm:
     """pinned, device-mapped host mirror of a batch's slot layout: numpy view int16 [S][stride] on the
     host, `.dev` for cmhip_batch_run_slots"""
@@ -458,6 +520,11 @@ def node_unique_id():
     return bytes(buf)
 
 
+def node_runtime():
+    """'hip=<path> rccl=<path>': the HIP runtime the engine is bound to and the librccl it resolved"""
+    return lib.cmhip_node_runtime().decode()
+
+
 def node_merge_host(records):
     """SUM / MAX of per-rank node records on the host (the no-collective form)"""
     w = np.ascontiguousarray(records, dtype=np.int64).reshape(-1, NODE_WORDS)
@@ -487,6 +554,9 @@ class Node:
             self.close()
         except Exception:
             pass
+
+    def ranks(self):
+        return lib.cmhip_node_ranks(self.h)
 
     def partial(self, batch, set_, slot, first_global=0, global_step=1):
         _check("node_partial", lib.cmhip_node_partial(self.h, batch.h, set_, slot, first_global, global_step))

@@ -73,6 +73,53 @@ extern "C" int cmhip_device_synchronize(int device)
     return COOLMIC_ERROR_NONE;
 }
 
+extern "C" int cmhip_device_mem_info(int device, size_t *free_bytes, size_t *total_bytes)
+{
+    if (device < 0 || device >= cmhip_device_count())
+        return fail(COOLMIC_ERROR_INVAL, "device_mem_info: no HIP device %d", device);
+    size_t f = 0, t = 0;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes)
+        *free_bytes = f;
+    if (total_bytes)
+        *total_bytes = t;
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" void *cmhip_device_alloc(int device, size_t bytes)
+{
+    void *p = nullptr;
+    if (device < 0 || device >= cmhip_device_count() || bytes == 0 || hipSetDevice(device) != hipSuccess ||
+        hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(COOLMIC_ERROR_NOMEM, "cmhip_device_alloc: %zu bytes on device %d", bytes, device);
+        return nullptr;
+    }
+    if (hipMemset(p, 0, bytes) != hipSuccess) {
+        (void)hipFree(p);
+        fail(COOLMIC_ERROR_GENERIC, "cmhip_device_alloc: clearing failed");
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void cmhip_device_free(int device, void *p)
+{
+    if (p && hipSetDevice(device) == hipSuccess)
+        (void)hipFree(p);
+}
+
+extern "C" int cmhip_device_read(int device, void *dst_host, const void *src_device, size_t bytes)
+{
+    if (!dst_host || !src_device)
+        return fail(COOLMIC_ERROR_FAULT, "device_read: NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
+    return COOLMIC_ERROR_NONE;
+}
+
 // ---------------------------------------------------------------------------
 // the batch object
 
@@ -116,6 +163,7 @@ struct cmhip_batch {
     EqParam *d_eq;
     EqState *d_eqstate;
     unsigned long long *d_sink;
+    long long *d_node_scratch;             // one node record, for cmhip_batch_vu_node_record (made on first use)
     unsigned long long *d_dbg;             // 64 words, written only by diagnostic builds
 
     std::vector<StreamParam> h_param;
@@ -144,6 +192,7 @@ struct cmhip_batch {
     unsigned int timing_every, timing_count;     // every n-th run carries the events (cmhip_batch_timing)
     std::vector<EventPair> ev_used, ev_free;
     RunTune tune;                          // launcher knobs, read once at creation
+    cmhip_placement_t place;               // what the placement search did (cmhip_batch_placement)
     bool vu_off;                           // runs leave the windows alone for now (cmhip_batch_vu_pause)
 };
 
@@ -167,9 +216,10 @@ static RunTune read_tune()
         if (v == 1 || v == 4 || v == 8)
             t.fast_nw = (uint32_t)v;
     }
+    t.place_env = -1;
     if (const char *e = getenv("CMHIP_PLACE")) {
-        t.place_off = atoi(e) == 0 ? 1u : 0u;
-        t.place_always = atoi(e) == 2 ? 1u : 0u;
+        const int v = atoi(e);
+        t.place_env = v <= 0 ? 0 : (v >= 2 ? 2 : 1);
     }
     if (getenv("CMHIP_PLACE_DEBUG"))
         t.place_debug = 1;
@@ -286,6 +336,7 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     (void)hipFree(b->d_eq);
     (void)hipFree(b->d_eqstate);
     (void)hipFree(b->d_sink);
+    (void)hipFree(b->d_node_scratch);
     (void)hipFree(b->d_dbg);
     for (int i = 0; i < 2; i++)
         if (b->h_snap2[i])
@@ -306,9 +357,11 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
 // three kinds; reads and writes that go to the same kind get in each other's way, and of the pairs
 // of different kinds one is better than the others).  Nothing but the virtual address is visible from
 // here, so the arrays are chosen by probing (place_arrays_apart, below): more candidates behind spacer
-// allocations, the batch's own run on every pair of them.  Only for arrays of 256 MiB and more, only
-// while the card has the room, allocations stop after 0.3 s, once per device and process
-// (place_search_allowed), off with CMHIP_PLACE=0.
+// allocations, the batch's own run on every pair of them.
+// The search is the CALLER's decision (CMHIP_PLACE_SEARCH in the batch's flags): a library must not, by
+// default, take tens of GiB for a moment and seconds of a constructor.  Only for arrays of 256 MiB and
+// more, never more than PLACE_BUDGET_FRAC of the memory reported free, allocations stop after 0.3 s;
+// what it did is in cmhip_batch_placement().
 constexpr size_t PLACE_MIN_BYTES = 256ull << 20;
 // Spacers before candidates 2, 3, ...: 68 GiB in all reach past two whole stretches.  (Larger ones reach further
 // -- 4 ... 32 GiB, 124 in all, found the best kind of pair more often -- but allocating from memory that this or
@@ -316,8 +369,8 @@ constexpr size_t PLACE_MIN_BYTES = 256ull << 20;
 // 16-32 GiB were seen to take 3-6 s.)
 constexpr size_t PLACE_SPACER_GIB[] = {0, 4, 8, 16, 16, 24};
 constexpr int PLACE_TRIES = 6;
-constexpr size_t PLACE_SPACER_SUM = (4ull + 8 + 16 + 16 + 24) << 30;
 constexpr double PLACE_BUDGET_S = 0.3;
+constexpr double PLACE_BUDGET_FRAC = 0.5;
 
 // a probe: the batch's own run (as created: no gain, no maps), full slots, from one candidate into another
 static double place_probe_ms(cmhip_batch_t *b, const void *src, void *dst, hipEvent_t e0, hipEvent_t e1)
@@ -350,19 +403,23 @@ static double place_probe_ms(cmhip_batch_t *b, const void *src, void *dst, hipEv
     if (hipEventRecord(e1, b->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
         hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
         return -1.;
+    b->place.probe_launches += n + 2;
     return (double)ms / n;
 }
 
-// One search per device and process (CMHIP_PLACE=2: for every batch): the spacers are 68 GiB that go back to
-// the driver, and allocating from memory the process has freed is slow on this driver (see PLACE_SPACER_GIB).
+// Who searches: a batch created with CMHIP_PLACE_SEARCH, always (the caller asked).  $CMHIP_PLACE, for
+// experiments: 0 nobody, 1 also the first large batch of a device in this process without the flag, 2 every
+// large batch.
 static bool place_search_allowed(const cmhip_batch_t *b)
 {
     static std::mutex mu;
     static bool searched[64];
-    if (b->tune.place_off)
+    if (b->tune.place_env == 0)
         return false;
-    if (b->tune.place_always)
+    if ((b->d.flags & CMHIP_PLACE_SEARCH) || b->tune.place_env == 2)
         return true;
+    if (b->tune.place_env != 1)
+        return false;
     std::lock_guard<std::mutex> g(mu);
     const int d = b->d.device;
     if (d < 0 || d >= 64 || searched[d])
@@ -385,21 +442,38 @@ static int place_arrays_apart(cmhip_batch_t *b, size_t bytes)
     int n = 2, in = 0, out = 1;
     size_t free_b = 0, total_b = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const size_t room = PLACE_SPACER_SUM + (size_t)(PLACE_TRIES - 1) * bytes + (8ull << 30);
+    cmhip_placement_t &rec = b->place;
+    rec.chosen_in = 0;
+    rec.chosen_out = 1;
+    rec.candidates = 2;
     if (bytes >= PLACE_MIN_BYTES && place_search_allowed(b) && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
-        free_b >= room && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         probed = true;
+        rec.searched = 1;
+        rec.bytes_free_before = free_b;
+        // never more than a stated share of what the card reports free, spacers and candidates together:
+        // on a fuller card the search reaches less far (fewer candidates), it does not crowd a neighbour out
+        const size_t budget = (size_t)((double)free_b * PLACE_BUDGET_FRAC);
+        size_t asked = 0;
         // (allocations of this size are normally a few milliseconds; from memory that has been used and freed
         // the driver has been seen to take seconds: then what there is by then decides)
         const auto t_begin = std::chrono::steady_clock::now();
         auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
         for (int k = 1; k < PLACE_TRIES && elapsed() <= PLACE_BUDGET_S; k++) {
-            if (hipMalloc(&spacer[n], PLACE_SPACER_GIB[k] << 30) != hipSuccess || hipMalloc(&cand[n], bytes) != hipSuccess) {
+            const size_t sp = PLACE_SPACER_GIB[k] << 30;
+            if (asked + sp + bytes > budget)
+                break;
+            if (hipMalloc(&spacer[n], sp) != hipSuccess || hipMalloc(&cand[n], bytes) != hipSuccess) {
                 (void)hipGetLastError();                  // no room after all
+                if (spacer[n])
+                    asked += sp;
                 break;
             }
+            asked += sp + bytes;
             n++;
         }
+        rec.bytes_requested = asked;
+        rec.candidates = n;
         // Samples that are not zero: a tile of silence adds nothing to its window and skips its atomics, and
         // without them the kinds of pairs lie closer together (3.5 % instead of 5 %: probes on cleared arrays
         // took a pair of one kind for a good one).
@@ -435,12 +509,19 @@ static int place_arrays_apart(cmhip_batch_t *b, size_t bytes)
         // taken if it is 2 % faster than that (a pair of the best kind is 5-8 % faster than one of one kind, a
         // middling one 3 %; moving the arrays for nothing costs nothing)
         std::sort(refs, refs + nref);
+        if (nref)
+            rec.first_pair_ms = refs[nref / 2];
+        rec.best_pair_ms = tbest;
         if (nref && tbest > 0. && tbest < 0.98 * refs[nref / 2]) {
             in = bi;
             out = bj;
         }
+        rec.chosen_in = in;
+        rec.chosen_out = out;
+        rec.search_ms = 1e3 * elapsed();
         if (b->tune.place_debug)
-            fprintf(stderr, "cmhip place: input = candidate %d, output = candidate %d, %.0f ms\n", in, out, 1e3 * elapsed());
+            fprintf(stderr, "cmhip place: input = candidate %d, output = candidate %d, %.0f ms, %.1f GiB asked of %.1f free\n",
+                    in, out, rec.search_ms, (double)asked / (1ull << 30), (double)free_b / (1ull << 30));
     }
     if (e0)
         (void)hipEventDestroy(e0);
@@ -464,6 +545,14 @@ static int place_arrays_apart(cmhip_batch_t *b, size_t bytes)
             HIP_TRY(hipMemsetAsync(b->d_vu2[i], 0, b->d.streams * sizeof(VuState), b->stream));
     if (b->d_f32)
         HIP_TRY(hipMemsetAsync(b->d_f32, 0, b->d.streams * b->d.channels * b->plane * sizeof(float), b->stream));
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_placement(const cmhip_batch_t *b, cmhip_placement_t *out)
+{
+    if (!b || !out)
+        return fail(COOLMIC_ERROR_FAULT, "placement: NULL argument");
+    *out = b->place;
     return COOLMIC_ERROR_NONE;
 }
 
@@ -629,6 +718,7 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->d_eq = nullptr;
     b->d_eqstate = nullptr;
     b->d_sink = nullptr;
+    b->d_node_scratch = nullptr;
     b->d_dbg = nullptr;
     b->h_snap2[0] = b->h_snap2[1] = nullptr;
     b->snap_event2[0] = b->snap_event2[1] = nullptr;
@@ -650,6 +740,9 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->timing_every = 1;
     b->timing_count = 0;
     b->tune = read_tune();
+    memset(&b->place, 0, sizeof(b->place));
+    b->place.chosen_out = 1;
+    b->place.candidates = 2;
     b->vu_off = false;
     if (batch_init(b) != COOLMIC_ERROR_NONE) {
         cmhip_batch_free(b);
@@ -1436,6 +1529,27 @@ extern "C" int cmhip_batch_vu_node_partial(cmhip_batch_t *b, void *dst_device,
         return COOLMIC_ERROR_GENERIC;
     long long *dst = (long long *)dst_device;
     return cmhip_batch_node_partial_split(b, dst, dst + CMHIP_NODE_SUM_WORDS, first_global, global_step, 1);
+}
+
+extern "C" int cmhip_batch_vu_node_record(cmhip_batch_t *b, int64_t *words_host, uint64_t first_global,
+                                          uint64_t global_step)
+{
+    if (!b || !words_host)
+        return fail(COOLMIC_ERROR_FAULT, "vu_node_record: NULL argument");
+    if (!(b->d.flags & CMHIP_VU))
+        return fail(COOLMIC_ERROR_INVAL, "vu_node_record: batch without VU");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    if (!b->d_node_scratch)
+        HIP_TRY(hipMalloc((void **)&b->d_node_scratch, CMHIP_NODE_WORDS * sizeof(long long)));
+    const int rc = cmhip_batch_node_partial_split(b, b->d_node_scratch, b->d_node_scratch + CMHIP_NODE_SUM_WORDS,
+                                                  first_global, global_step, 1);
+    if (rc != COOLMIC_ERROR_NONE)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(words_host, b->d_node_scratch, CMHIP_NODE_WORDS * sizeof(long long),
+                           hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return COOLMIC_ERROR_NONE;
 }
 
 // internal (node.hip): the same record with its sums and its keys in two places

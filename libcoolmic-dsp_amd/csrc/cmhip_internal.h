@@ -93,8 +93,8 @@ struct RunTune {
     uint32_t wide4_f32;
     uint32_t rows_rpt;
     uint32_t fast_nw;              // CMHIP_FAST_NW in {1, 4, 8}: waves per workgroup of the mono / stereo forms with a window
-    uint32_t place_off;            // CMHIP_PLACE=0: the PCM output array stays where hipMalloc first puts it
-    uint32_t place_always;         // CMHIP_PLACE=2: search for every batch, not only the first of a device
+    int32_t  place_env;            // CMHIP_PLACE: -1 unset (only batches created with CMHIP_PLACE_SEARCH search), 0 never,
+                                   // 1 the first large batch of a device also without the flag, 2 every large batch
     uint32_t place_debug;          // CMHIP_PLACE_DEBUG: the probe times of the placement search on stderr
 };
 

@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <string>
 #include <vector>
 
 using namespace cmhip;
@@ -49,15 +50,33 @@ Rccl g_rccl;
 std::once_flag g_rccl_once;
 char g_rccl_error[256];
 
+char g_rccl_path[512], g_hip_path[512];
+
 void load_rccl()
 {
-    // $CMHIP_RCCL_LIB first; then the soname (an already loaded librccl -- e.g. the one inside a
-    // torch wheel that the process imported -- is found by it); then the ROCm tree
-    const char *names[] = {getenv("CMHIP_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    // $CMHIP_RCCL_LIB first; then the librccl that lies NEXT TO the HIP runtime this engine is bound to
+    // (dladdr of a HIP entry point): a process may hold two HIP runtimes -- the system's and the one inside
+    // a torch wheel -- each with a librccl of the same soname, and device pointers of one runtime mean
+    // nothing to a librccl bound to the other.  By soname only after that.
+    std::string a, b;
+    Dl_info info;
+    if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+        snprintf(g_hip_path, sizeof(g_hip_path), "%s", info.dli_fname);
+        std::string dir(info.dli_fname);
+        const size_t cut = dir.rfind('/');
+        if (cut != std::string::npos) {
+            a = dir.substr(0, cut) + "/librccl.so.1";
+            b = dir.substr(0, cut) + "/librccl.so";
+        }
+    }
+    const char *names[] = {getenv("CMHIP_RCCL_LIB"), a.c_str(), b.c_str(), "librccl.so.1",
+                           "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     void *h = nullptr;
     for (const char *n : names) {
-        if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
+        if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) {
+            snprintf(g_rccl_path, sizeof(g_rccl_path), "%s", n);
             break;
+        }
     }
     if (!h) {
         snprintf(g_rccl_error, sizeof(g_rccl_error), "librccl not found: %s", dlerror());
@@ -230,6 +249,15 @@ extern "C" cmhip_node_t *cmhip_node_new(int device, int nranks, int rank, const 
 }
 
 extern "C" int cmhip_node_ranks(const cmhip_node_t *n) { return n ? n->nranks : 0; }
+
+// diagnostics: which HIP runtime the engine is bound to and which librccl it resolved (loads librccl)
+extern "C" const char *cmhip_node_runtime(void)
+{
+    static char text[1100];
+    const Rccl *rc = rccl();
+    snprintf(text, sizeof(text), "hip=%s rccl=%s", g_hip_path[0] ? g_hip_path : "?", rc ? g_rccl_path : g_rccl_error);
+    return text;
+}
 
 extern "C" int cmhip_node_partial(cmhip_node_t *n, cmhip_batch_t *b, unsigned int set, unsigned int slot,
                                   uint64_t first_global, uint64_t global_step)

@@ -3,11 +3,18 @@ import os
 import sys
 
 import pytest
-import torch  # noqa: F401  (before the HIP library: torch bundles its own HIP runtime)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+# The engine FIRST, before any test module can import torch: whatever is loaded first decides which HIP
+# runtime the engine is bound to (the system's ROCm 7.2 in /opt/rocm, as under bench.py -- or, torch first,
+# the ROCm 7.0 copy inside the torch wheel, whose direct dispatch DESIGN 5 measured behaving differently).
+# The GPU tests use no torch at all; tests/test_multirank_gloo.py imports it for gloo on the CPU only.
+import __graft_entry__ as _ge  # noqa: E402
+
+_ge.load_package()
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

@@ -9,7 +9,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch  # noqa: F401
 import __graft_entry__ as ge
 from oracle import oracle_ffi as of
 

@@ -35,6 +35,12 @@ def test_self_launch_prints_one_line_from_rank0(n, workload):
     assert out["clock_max_over_ranks"] == float(n)          # rank r reports 1 + r: the slowest counts
     assert out["node_id_same_on_all_ranks"] is True
     assert out["config"]["workload"] == workload
+    # every rank left the warm-up loop after the same chunk (the decision is rank 0's, broadcast): ranks that
+    # issue collectives in their steps issue the same number of them
+    assert len(set(out["warmup_steps_all_ranks"])) == 1 and out["warmup_steps_all_ranks"][0] > 1
+    # configs 4 / 5 at this N ride on the driver's one command: the keys of their legs
+    for key in ("rccl_ranks", "ms_per_step_c4", "ms_per_step_c5", "matches_host_merge"):
+        assert key in out["node_vu"], key
 
 
 def test_single_rank_needs_no_launcher_and_no_torch():
@@ -42,6 +48,26 @@ def test_single_rank_needs_no_launcher_and_no_torch():
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     out = json.loads(p.stdout.decode().strip())
     assert out["n_gpus"] == 1 and "ranks_seen" not in out
+
+
+def test_ranks_that_hang_are_ended_at_the_deadline():
+    """every rank alive, one of them stuck for ever (a collective its peer never issued, a hung GPU): the
+    launch has a wall-clock deadline, names the ranks it ends and fails -- it does not poll for ever"""
+    import time
+    t0 = time.time()
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1"],
+             {"COOLMIC_BENCH_DRYRUN": "1", "COOLMIC_BENCH_DRYRUN_HANG_RANK": "1", "COOLMIC_BENCH_DEADLINE_S": "25"},
+             timeout=120)
+    assert p.returncode == 124, p.stderr.decode()[-2000:]
+    assert p.stdout.decode().strip() == ""
+    assert b"still running" in p.stderr and time.time() - t0 < 80
+
+
+def test_no_self_launch_under_a_profiler_preload():
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1"],
+             {"COOLMIC_BENCH_DRYRUN": "1", "ROCP_TOOL_LIBRARIES": "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"}, timeout=60)
+    assert p.returncode == 2 and b"Profile one rank directly" in p.stderr
+    assert p.stdout.decode().strip() == ""
 
 
 def test_a_failing_rank_fails_the_launch():

@@ -5,6 +5,7 @@ Bar: bit-exact for int16 PCM, VU accumulators and peaks; dB values bit-equal dou
 (they are finished on the host with the reference's own formula).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -513,7 +514,6 @@ def test_results_for_all_streams_and_snapshot_overlap(gpu, oracle):
 def test_node_partial_matches_host_merge(gpu, oracle):
     """config 5's per-GPU record; two 'ranks' emulated as two batches on this GPU and
     combined on the host the way the all-reduce combines them (SUM / MAX)"""
-    import torch
     cm = gpu
     C, T, S = 2, 4096, 16
     N = 2
@@ -524,10 +524,13 @@ def test_node_partial_matches_host_merge(gpu, oracle):
         assert b.set_gain(-1, 2, 1000, [750, 1250]) == 0
         b.generate(cm.GEN_NOISE, 31337, T, first_global=rank, global_step=N)
         b.run(T)
-        dst = torch.zeros(cm.NODE_WORDS, dtype=torch.int64, device="cuda:0")
-        b.node_partial(dst.data_ptr(), first_global=rank, global_step=N)
+        dst = cm.DeviceWords(cm.NODE_WORDS)
+        b.node_partial(dst.dev, first_global=rank, global_step=N)
         b.sync()
-        words.append(dst.cpu().numpy())
+        words.append(dst.read())
+        dst.free()
+        # the host form of the same record (for a host that brings its own collective)
+        assert np.array_equal(b.node_record(first_global=rank, global_step=N), words[-1])
         for s in range(S // N):
             gs = rank + N * s
             allblocks.append(_oracle_block(oracle, oracle.lcg(31337 + gs, T * C), C,
@@ -559,23 +562,28 @@ def test_node_exchange_through_rccl_one_rank(gpu, oracle):
     hold): records of three blocks in slots of both sets, all-reduced by ncclAllReduce(int64, sum) +
     ncclAllReduce(uint64, max), fetched, and equal to the records cmhip_batch_vu_node_partial writes
     in one piece -- which test_node_partial_matches_host_merge pins against the oracle"""
-    import torch
     cm = gpu
     C, T, S = 2, 4096, 24
     node = cm.Node(0, 1, 0, cm.node_unique_id(), max_records=3)
     assert cm.lib.cmhip_node_ranks(node.h) == 1
+    # librccl comes from next to the HIP runtime the engine is bound to -- the system's (conftest loads the
+    # engine before anything brings torch's copies): the runtime pair bench.py runs on
+    hip_path, rccl_path = (kv.split("=", 1)[1] for kv in cm.node_runtime().split(" "))
+    assert os.path.dirname(os.path.realpath(hip_path)) == os.path.dirname(os.path.realpath(rccl_path)), cm.node_runtime()
+    assert "/torch/" not in hip_path, cm.node_runtime()
     b = cm.Batch(S, C, T, flags=cm.VU)
     assert b.set_gain(-1, 2, 1000, [750, 1250]) == 0
     direct = []
     for k in range(4):
         b.generate(cm.GEN_NOISE, 99, T, first_global=3, global_step=5, frame_offset=k * T)
         b.run(T)
-        dst = torch.zeros(cm.NODE_WORDS, dtype=torch.int64, device="cuda:0")
-        b.node_partial(dst.data_ptr(), first_global=3, global_step=5)
+        dst = cm.DeviceWords(cm.NODE_WORDS)
+        b.node_partial(dst.dev, first_global=3, global_step=5)
         set_, slot = (0, k) if k < 3 else (1, 0)
         node.partial(b, set_, slot, first_global=3, global_step=5)
         b.sync()
-        direct.append(dst.cpu().numpy())
+        direct.append(dst.read())
+        dst.free()
         b.vu_reset(-1)
         if k == 2:
             node.allreduce(0, 3, after=b)
@@ -634,16 +642,27 @@ def test_full_size_config2_properties(gpu, oracle):
     v.close()
 
 
-@pytest.mark.parametrize("place", ["0", "2"])
+@pytest.mark.parametrize("place", ["off", "flag", "env2"])
 def test_arrays_placed_apart_hold_the_same_results(gpu, oracle, place, monkeypatch):
-    """A batch with PCM arrays of 256 MiB and more may move both of them at the end of its creation, to
-    where its own run is fastest (`place_arrays_apart`; $CMHIP_PLACE=2 makes every batch search,
-    0 none).  Whatever it chose, the probes leave nothing behind: uploads, the input read back, PCM and the
-    windows of the first launch against the oracle."""
+    """A batch created with CMHIP_PLACE_SEARCH (PCM arrays of 256 MiB and more) may move both of them at
+    the end of its creation, to where its own run is fastest (`place_arrays_apart`, DESIGN 4.1;
+    $CMHIP_PLACE=2 makes every batch search, 0 none).  Whatever it chose, the probes leave nothing behind:
+    uploads, the input read back, PCM and the windows of the first launch against the oracle; and the
+    search keeps inside its stated budget, half of the memory the card reported free."""
     cm = gpu
-    monkeypatch.setenv("CMHIP_PLACE", place)
+    monkeypatch.delenv("CMHIP_PLACE", raising=False)
+    if place == "env2":
+        monkeypatch.setenv("CMHIP_PLACE", "2")
     S, C, T = 1024, 2, 65536                      # 256 MiB per array
-    b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU)
+    b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU | (cm.PLACE_SEARCH if place == "flag" else 0))
+    rec = b.placement()
+    assert rec["searched"] == (place != "off"), rec
+    if rec["searched"]:
+        assert 2 <= rec["candidates"] <= 7 and rec["probe_launches"] > 0 and rec["first_pair_ms"] > 0
+        assert rec["GiB_requested"] <= 0.5 * rec["GiB_free_before"] + 0.01, rec
+        assert rec["chosen"][0] != rec["chosen"][1] and max(rec["chosen"]) < rec["candidates"]
+    else:
+        assert rec["probe_launches"] == 0 and rec["GiB_requested"] == 0 and rec["chosen"] == [0, 1]
     for s in (0, 511, 1023):                      # nothing in the windows, zeros in the arrays
         assert b.vu_raw(s)[2] == 0
         assert not b.download(s, 64).any()
@@ -666,22 +685,41 @@ def test_arrays_placed_apart_hold_the_same_results(gpu, oracle, place, monkeypat
     b.close()
 
 
+def test_no_placement_search_unless_asked_for(gpu, monkeypatch):
+    """The library's default: creating a large batch is two allocations and no probe launch -- fast, and
+    the card's free memory afterwards is down by the batch's own arrays and tables, nothing else."""
+    import time
+    cm = gpu
+    monkeypatch.delenv("CMHIP_PLACE", raising=False)
+    warm = cm.Batch(1, 2, 64, flags=cm.OUT_PCM | cm.VU)       # the device's first batch pays the runtime's start
+    warm.close()
+    cm.device_synchronize(0)
+    free0, _ = cm.device_mem_info(0)
+    S, C, T = 1024, 2, 65536                      # 256 MiB per array: large enough for a search
+    t0 = time.perf_counter()
+    b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU)
+    dt = time.perf_counter() - t0
+    free1, _ = cm.device_mem_info(0)
+    rec = b.placement()
+    own = 2 * S * b.stride * 2
+    assert not rec["searched"] and rec["probe_launches"] == 0 and rec["GiB_requested"] == 0, rec
+    assert dt < 0.5, dt
+    assert own <= free0 - free1 <= own + (64 << 20), (free0 - free1, own)
+    b.close()
+
+
 def test_full_size_config4_total_on_one_gpu(gpu, oracle):
     """BASELINE configs 4/5 hold 65 536 mono streams; all of them on ONE GPU at 65 536 frames are
     8 GiB of PCM per array, so slot offsets pass 2^32 bytes (stream 32 768 starts at exactly 4 GiB).
     Sampled streams on both sides of that line against the oracle; the node-global record of the
     batch against the host merge of all 65 536 per-stream windows (a checksum of checksums)."""
-    import torch
     cm = gpu
     S, C, T = 65536, 1, 65536
     b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU)
     assert b.set_gain(-1, 1, 1000, [900]) == 0
     b.generate(cm.GEN_NOISE, 12345, T)
     b.run(T)
-    dst = torch.zeros(cm.NODE_WORDS, dtype=torch.int64, device="cuda:0")
-    b.node_partial(dst.data_ptr())
-    b.sync()
-    rc, node = cm.node_finish(dst.cpu().numpy(), C)
+    rc, node = cm.node_finish(b.node_record(), C)
     assert rc == 0 and node.frames == S * T
     total, top = 0, 0
     for s in range(S):
