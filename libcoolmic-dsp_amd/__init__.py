@@ -208,6 +208,10 @@ for _name, (_res, _args) in SIGNATURES.items():
 # not in a public header: host-logic test hooks
 lib.cmhip_test_magic.restype = None
 lib.cmhip_test_magic.argtypes = [C.c_uint16, _P(C.c_uint32), _P(C.c_uint32)]
+lib.cmhip_debug_run_count.restype = C.c_ulonglong
+lib.cmhip_debug_run_count.argtypes = []
+lib.coolmic_debug_vumeter_mode.restype = C.c_int
+lib.coolmic_debug_vumeter_mode.argtypes = [_vp]
 lib.coolmic_sine_period.restype = C.c_int
 lib.coolmic_sine_period.argtypes = [C.c_uint32, _vp, _P(C.c_size_t)]
 
@@ -723,6 +727,10 @@ class Vumeter:
 
     def reset(self):
         return lib.coolmic_vumeter_reset(self.ptr)
+
+    def mode(self):
+        """test hook: 0 own batch, 1 shares the launch of the transform right above, 2 shares it through a tee"""
+        return lib.coolmic_debug_vumeter_mode(self.ptr)
 
     def unref(self):
         if self.ptr:

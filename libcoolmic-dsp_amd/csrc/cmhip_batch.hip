@@ -17,12 +17,14 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <thread>
 #include <vector>
 
 #include "work_pool.h"
+#include "host_internal.h"
 
 extern "C" int coolmic_sine_period(uint_least32_t rate, int16_t *table, size_t *samples);
 
@@ -164,6 +166,10 @@ struct cmhip_batch {
     EqState *d_eqstate;
     unsigned long long *d_sink;
     long long *d_node_scratch;             // one node record, for cmhip_batch_vu_node_record (made on first use)
+    // ring mode (cmhip_batch_vu_ring): every run accumulates into a window of its own
+    VuState *d_ring, *h_ring;              // ring_slots x S windows on the device / pinned staging for a fetch
+    unsigned int ring_slots;
+    uint64_t ring_seq;                     // sequence number of the next run
     unsigned long long *d_dbg;             // 64 words, written only by diagnostic builds
 
     std::vector<StreamParam> h_param;
@@ -337,6 +343,9 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     (void)hipFree(b->d_eqstate);
     (void)hipFree(b->d_sink);
     (void)hipFree(b->d_node_scratch);
+    (void)hipFree(b->d_ring);
+    if (b->h_ring)
+        (void)hipHostFree(b->h_ring);
     (void)hipFree(b->d_dbg);
     for (int i = 0; i < 2; i++)
         if (b->h_snap2[i])
@@ -719,6 +728,9 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->d_eqstate = nullptr;
     b->d_sink = nullptr;
     b->d_node_scratch = nullptr;
+    b->d_ring = b->h_ring = nullptr;
+    b->ring_slots = 0;
+    b->ring_seq = 0;
     b->d_dbg = nullptr;
     b->h_snap2[0] = b->h_snap2[1] = nullptr;
     b->snap_event2[0] = b->snap_event2[1] = nullptr;
@@ -761,6 +773,10 @@ extern "C" int cmhip_debug_read(cmhip_batch_t *b, unsigned long long *out)
         return COOLMIC_ERROR_GENERIC;
     return COOLMIC_ERROR_NONE;
 }
+
+// test hook: runs launched by this process so far (tests count launches per pull with it)
+static std::atomic<unsigned long long> g_runs{0};
+extern "C" unsigned long long cmhip_debug_run_count(void) { return g_runs.load(); }
 
 // test hook: the division constants for a scale (host logic, needs no GPU)
 extern "C" void cmhip_test_magic(uint16_t scale, uint32_t *magic, uint32_t *shift)
@@ -1249,6 +1265,11 @@ static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per
         return COOLMIC_ERROR_GENERIC;
 
     const bool vu = (b->d.flags & CMHIP_VU) != 0 && !b->vu_off;
+    // ring mode: this run's window is a cleared slot of its own (sample indices start at 0: slot 0 of
+    // VuState::samples is read, slot 1 written)
+    const bool ring = vu && b->ring_slots != 0;
+    VuState *const window = ring ? b->d_ring + (size_t)(b->ring_seq % b->ring_slots) * b->d.streams : b->d_vu;
+    const uint32_t parity = ring ? 0u : b->parity;
     EventPair ev{};                          // timing: the events take the kernel's own start and end
     const bool timed = b->timing && b->timing_count++ % b->timing_every == 0;
     if (timed) {
@@ -1267,14 +1288,14 @@ static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per
         a.param = b->d_param;
         a.eq = b->d_eq;
         a.state = b->d_eqstate;
-        a.vu = vu ? b->d_vu : nullptr;
+        a.vu = vu ? window : nullptr;
         a.nframes = frames_per_stream ? b->d_nframes : nullptr;
         a.frames = (uint32_t)frames;
         a.streams = b->d.streams;
         a.channels = b->d.channels;
         a.nsec = b->nsec;
         a.whole_streams = (slots_out == slots_in && !b->all_identity) ? 1u : 0u;
-        a.parity = b->parity;
+        a.parity = parity;
         a.dbg = b->d_dbg;
         a.stride = b->stride;
         a.plane = b->plane;
@@ -1288,7 +1309,7 @@ static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per
         a.f32 = b->d_f32;
         a.param = b->d_param;
         a.gshort = b->d_gshort;
-        a.vu = vu ? b->d_vu : nullptr;
+        a.vu = vu ? window : nullptr;
         a.nframes = frames_per_stream ? b->d_nframes : nullptr;
         a.frames = (uint32_t)frames;
         a.streams = b->d.streams;
@@ -1298,13 +1319,16 @@ static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per
         a.chunks = 0;                      // the launcher sizes the tiles per kernel variant
         a.identity_maps = b->all_identity ? 1u : 0u;
         a.identity_gains = b->all_gain_identity ? 1u : 0u;
-        a.parity = b->parity;
+        a.parity = parity;
         HIP_TRY(launch_run(a, b->tune, b->stream, ev.a, ev.b));
         b->in_flight = true;
     }
     if (timed)
         b->ev_used.push_back(ev);
-    if (vu)
+    g_runs.fetch_add(1, std::memory_order_relaxed);
+    if (ring)
+        b->ring_seq++;
+    else if (vu)
         b->parity ^= 1u;                   // the kernel wrote the other samples slot
     return COOLMIC_ERROR_NONE;
 }
@@ -1512,6 +1536,130 @@ extern "C" int cmhip_batch_vu_raw(cmhip_batch_t *b, unsigned int stream, int64_t
     }
     if (frames)
         *frames = v.samples[b->parity] / b->d.channels;
+    return COOLMIC_ERROR_NONE;
+}
+
+// ---------------------------------------------------------------------------
+// per-launch window records (engine internal, host_internal.h): transform.c / vumeter.c
+
+static void raw_from_state(const VuState &v, unsigned parity, cmhip_vu_raw_t *out)
+{
+    static_assert(MAX_CH == 16, "cmhip_vu_raw_t holds sixteen channels");
+    for (unsigned c = 0; c < MAX_CH; c++) {
+        out->power[c] = v.power[c];
+        out->key[c] = v.key[c];
+    }
+    out->samples = v.samples[parity];
+}
+
+extern "C" CMHIP_INTERNAL int cmhip_batch_vu_ring(cmhip_batch_t *b, unsigned int slots)
+{
+    if (!b)
+        return fail(COOLMIC_ERROR_FAULT, "vu_ring: batch is NULL");
+    if (!(b->d.flags & CMHIP_VU) || slots > 65536)
+        return fail(COOLMIC_ERROR_INVAL, "vu_ring: batch without VU, or too many slots");
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (slots != b->ring_slots) {
+        (void)hipFree(b->d_ring);
+        if (b->h_ring)
+            (void)hipHostFree(b->h_ring);
+        b->d_ring = b->h_ring = nullptr;
+        b->ring_slots = 0;
+        if (slots) {
+            const size_t bytes = (size_t)slots * b->d.streams * sizeof(VuState);
+            HIP_TRY(hipMalloc((void **)&b->d_ring, bytes));
+            HIP_TRY(hipHostMalloc((void **)&b->h_ring, bytes, hipHostMallocDefault));
+            b->ring_slots = slots;
+        }
+    }
+    if (b->ring_slots)
+        HIP_TRY(hipMemsetAsync(b->d_ring, 0, (size_t)b->ring_slots * b->d.streams * sizeof(VuState), b->stream));
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" CMHIP_INTERNAL uint64_t cmhip_batch_vu_ring_seq(const cmhip_batch_t *b) { return b ? b->ring_seq : 0; }
+
+extern "C" CMHIP_INTERNAL int cmhip_batch_vu_ring_fetch(cmhip_batch_t *b, uint64_t first_seq, unsigned int count,
+                                                        cmhip_vu_raw_t *out)
+{
+    if (!b || !out)
+        return fail(COOLMIC_ERROR_FAULT, "vu_ring_fetch: NULL argument");
+    if (!b->ring_slots || count == 0 || count > b->ring_slots || first_seq + count > b->ring_seq ||
+        b->ring_seq - first_seq > b->ring_slots)
+        return fail(COOLMIC_ERROR_INVAL, "vu_ring_fetch: runs %llu..+%u are not in the ring",
+                    (unsigned long long)first_seq, count);
+    if (use(b))
+        return COOLMIC_ERROR_GENERIC;
+    const size_t S = b->d.streams;
+    const unsigned first = (unsigned)(first_seq % b->ring_slots);
+    const unsigned n1 = count < b->ring_slots - first ? count : b->ring_slots - first;     // up to the wrap
+    HIP_TRY(hipMemcpyAsync(b->h_ring + (size_t)first * S, b->d_ring + (size_t)first * S, n1 * S * sizeof(VuState),
+                           hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemsetAsync(b->d_ring + (size_t)first * S, 0, n1 * S * sizeof(VuState), b->stream));
+    if (n1 < count) {
+        HIP_TRY(hipMemcpyAsync(b->h_ring, b->d_ring, (count - n1) * S * sizeof(VuState), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemsetAsync(b->d_ring, 0, (count - n1) * S * sizeof(VuState), b->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    for (unsigned i = 0; i < count; i++)
+        raw_from_state(b->h_ring[(size_t)((first + i) % b->ring_slots) * S], 1u, &out[i]);
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" CMHIP_INTERNAL int cmhip_batch_vu_raw_state(cmhip_batch_t *b, unsigned int stream, cmhip_vu_raw_t *out)
+{
+    if (!b || !out)
+        return fail(COOLMIC_ERROR_FAULT, "vu_raw_state: NULL argument");
+    if (stream >= b->d.streams || !(b->d.flags & CMHIP_VU))
+        return fail(COOLMIC_ERROR_INVAL, "vu_raw_state: stream out of range or batch without VU");
+    if (use(b) || settle_node(b))
+        return COOLMIC_ERROR_GENERIC;
+    VuState v;
+    HIP_TRY(hipMemcpyAsync(&v, b->d_vu + stream, sizeof(v), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    raw_from_state(v, b->parity, out);
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" CMHIP_INTERNAL void cmhip_vu_raw_merge(cmhip_vu_raw_t *acc, const cmhip_vu_raw_t *piece, unsigned int channels)
+{
+    for (unsigned c = 0; c < channels && c < MAX_CH; c++) {
+        acc->power[c] += piece->power[c];
+        uint64_t k = piece->key[c];
+        if (k) {                             // the piece's sample indices continue the window's
+            const uint64_t idx = (~(k >> 1) & KEY_IDX_MASK) + acc->samples;
+            k = (k & ~(KEY_IDX_MASK << 1)) | ((~idx & KEY_IDX_MASK) << 1);
+            if (k > acc->key[c])
+                acc->key[c] = k;
+        }
+    }
+    acc->samples += piece->samples;
+}
+
+extern "C" CMHIP_INTERNAL int cmhip_vu_raw_finish(const cmhip_vu_raw_t *w, unsigned int channels, unsigned int rate,
+                                                  coolmic_vumeter_result_t *out)
+{
+    if (!w || !out || channels == 0 || channels > MAX_CH)
+        return COOLMIC_ERROR_FAULT;
+    const unsigned long long frames = w->samples / channels;
+    if (frames == 0)
+        return COOLMIC_ERROR_INVAL;                      // ref: src/vumeter.c:198-199
+    memset(out, 0, sizeof(*out));
+    out->rate = rate;
+    out->channels = channels;
+    out->frames = (size_t)frames;
+    unsigned long long all = 0, best = 0;
+    for (unsigned c = 0; c < channels; c++) {
+        all += w->power[c];
+        out->channel_power[c] = power_db(w->power[c], frames);
+        out->channel_peak[c] = key_peak(w->key[c]);
+        if (w->key[c] > best)
+            best = w->key[c];
+    }
+    out->global_power = power_db(all, frames * channels);
+    out->global_peak = key_peak(best);
     return COOLMIC_ERROR_NONE;
 }
 

@@ -77,3 +77,12 @@ struct coolmic_transform *coolmic_iohandle_as_transform(coolmic_iohandle_t *h)
         return h->userdata;
     return NULL;
 }
+
+/* ... and a tee's reader handle: -> the reader's userdata for coolmic_tee_reader_upstream() */
+extern ssize_t coolmic_tee_reader_read(void *userdata, void *buffer, size_t len);
+void *coolmic_iohandle_as_tee_reader(coolmic_iohandle_t *h)
+{
+    if (h != NULL && h->read_fn == coolmic_tee_reader_read)
+        return h->userdata;
+    return NULL;
+}

@@ -17,6 +17,15 @@ struct coolmic_tee {
     unsigned char *buffer;
     size_t capacity, fill;
     size_t pos[COOLMIC_DSP_TEE_MAX_READERS];    /* read position of each reader in buffer */
+    /* Where the buffered bytes lie in the OUTPUT of an upstream transform (for a VU meter on one of the
+     * readers that shares the transform's launch, vumeter.c): buffer[0] is byte `stream_base` of what this tee has
+     * pulled since it was attached, and byte x of that is byte x + delta of the transform's output -- as long
+     * as nobody else reads the transform's handle in between; `discont` counts the times that broke (or the
+     * upstream changed), and whoever relies on the mapping stops relying on it then. */
+    uint64_t stream_base;
+    int64_t delta;
+    int delta_valid;
+    unsigned int discont;
 };
 
 typedef struct {
@@ -52,6 +61,8 @@ int coolmic_tee_attach_iohandle(coolmic_tee_t *self, coolmic_iohandle_t *handle)
     coolmic_ro_unref(self->in);
     self->in = handle;
     coolmic_ro_ref(handle);
+    self->delta_valid = 0;
+    self->discont++;
     return COOLMIC_ERROR_NONE;
 }
 
@@ -82,6 +93,7 @@ static void tee_make_room(coolmic_tee_t *t, size_t want)
     if (low > 0) {
         memmove(t->buffer, t->buffer + low, t->fill - low);
         t->fill -= low;
+        t->stream_base += low;
         for (i = 0; i < t->readers; i++)
             t->pos[i] -= low;
     }
@@ -92,6 +104,8 @@ static ssize_t tee_pull(coolmic_tee_t *t, size_t want)
 {
     size_t room;
     ssize_t got;
+    struct coolmic_transform *up;
+    uint64_t up_off = 0;
 
     tee_make_room(t, want);
     room = t->capacity - t->fill;
@@ -102,14 +116,25 @@ static ssize_t tee_pull(coolmic_tee_t *t, size_t want)
     }
     if (room > want)
         room = want;
+    up = coolmic_iohandle_as_transform(t->in);
+    if (up != NULL)
+        up_off = coolmic_transform_out_bytes(up);
     got = coolmic_iohandle_read(t->in, t->buffer + t->fill, room);
     if (got < 1)
         return got;
+    if (up != NULL) {                  /* these bytes are [up_off, up_off + got) of the transform's output */
+        const int64_t d = (int64_t)(up_off - (t->stream_base + t->fill));
+        if (t->delta_valid && d != t->delta)
+            t->discont++;              /* somebody else took bytes from the transform in between */
+        t->delta = d;
+        t->delta_valid = 1;
+    }
     t->fill += (size_t)got;
     return got;
 }
 
-static ssize_t tee_reader_read(void *userdata, void *buffer, size_t len)
+/* exported (not static) so that iohandle.c can recognise reader handles made here */
+ssize_t coolmic_tee_reader_read(void *userdata, void *buffer, size_t len)
 {
     tee_reader_t *r = userdata;
     coolmic_tee_t *t = r->tee;
@@ -171,8 +196,35 @@ coolmic_iohandle_t *coolmic_tee_get_iohandle(coolmic_tee_t *self, ssize_t index)
     coolmic_ro_ref(self);
     r->tee = self;
     r->index = (size_t)index;
-    h = coolmic_iohandle_new(NULL, igloo_RO_NULL, r, tee_reader_free, tee_reader_read, tee_reader_eof);
+    h = coolmic_iohandle_new(NULL, igloo_RO_NULL, r, tee_reader_free, coolmic_tee_reader_read, tee_reader_eof);
     if (h == NULL)
         tee_reader_free(r);
     return h;
+}
+
+/* ---- for a VU meter on a reader handle (internal: vumeter.c; declared in host_internal.h) -------- */
+
+/* the transform right above the tee of reader handle `userdata` (NULL: none), the position of that reader's
+ * next byte in the transform's output, and the discontinuity count to compare later */
+struct coolmic_transform *coolmic_tee_reader_upstream(void *userdata, uint64_t *next_off, unsigned int *discont)
+{
+    tee_reader_t *r = userdata;
+    coolmic_tee_t *t = r->tee;
+    struct coolmic_transform *up = coolmic_iohandle_as_transform(t->in);
+
+    if (up == NULL)
+        return NULL;
+    if (!t->delta_valid) {             /* nothing pulled from this upstream yet: the next pull continues its output */
+        t->delta = (int64_t)(coolmic_transform_out_bytes(up) - (t->stream_base + t->fill));
+        t->delta_valid = 1;
+    }
+    *next_off = (uint64_t)((int64_t)(t->stream_base + t->pos[r->index]) + t->delta);
+    *discont = t->discont;
+    return up;
+}
+
+unsigned int coolmic_tee_reader_discont(void *userdata)
+{
+    tee_reader_t *r = userdata;
+    return r->tee->discont;
 }

@@ -19,9 +19,22 @@
 #include <coolmic_hip.h>
 
 #include <pthread.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define TRANSFORM_SLICE_FRAMES 16384u
+#define TRANSFORM_RING_SLOTS   256u     /* windows of the last launches that stay on the device (records mode) */
+
+enum { VU_NONE = 0, VU_DIRECT = 1, VU_RECORDS = 2 };
+
+/* records mode: what one launch covered, and its window once it has been fetched */
+typedef struct {
+    uint64_t off;                      /* first byte, in bytes this transform's handle has returned */
+    uint32_t bytes;
+    uint64_t seq;                      /* the launch's sequence number in the batch's window ring */
+    int have;                          /* raw is valid (fetched from the device) */
+    cmhip_vu_raw_t raw;
+} transform_record_t;
 
 struct coolmic_transform {
     coolmic_ro_base_t base;
@@ -44,10 +57,26 @@ struct coolmic_transform {
                                         * once the values they were set with have reached the device */
 
     cmhip_batch_t *dev;                /* created at the first read that needs it */
-    int fused_vu;                      /* a VU meter sits directly on this transform's handle: the launch
-                                        * that transforms a block also accumulates its window (one launch
-                                        * per pull instead of two; coolmic_transform_fuse_vu) */
-    int vu_armed;                      /* ... for the read that is under way: it is the meter's own */
+    /* A VU meter downstream shares this transform's launch (one launch per pull instead of two).  All three
+     * fields are published under `lock` and read once per block (transform_process):
+     *   VU_DIRECT   the meter sits directly on this transform's handle: the launch accumulates the meter's
+     *               window beside its own arithmetic, for the reads the meter arms (coolmic_transform_fuse_vu);
+     *   VU_RECORDS  the meter sits behind a coolmic_tee_t (ref: src/simple.c:217-229) and may lag behind what
+     *               this transform has produced: every launch leaves a window record of its own, and the meter
+     *               merges the records of exactly the bytes it has consumed (coolmic_transform_records). */
+    int vu_mode;
+    int vu_armed;                      /* VU_DIRECT: the read that is under way is the meter's own */
+    int vu_reset_pending;              /* the window is to be cleared before the next block touches it */
+
+    uint64_t out_bytes;                /* bytes this transform's handle has returned so far */
+    /* VU_RECORDS (worker thread only): one descriptor per launch, oldest first, in a circular array */
+    transform_record_t *rec;
+    size_t rec_cap, rec_head, rec_count;
+    uint64_t rec_dropped;              /* descriptors dropped so far (absolute index of rec_head) */
+    uint64_t rec_cursor;               /* absolute index where the last lookup ended */
+    uint64_t rec_start;                /* out_bytes when the records were switched on */
+    uint64_t rec_fetched_seq;          /* ring windows below this sequence number have been fetched */
+    int ring_on;                       /* the device batch is in ring mode */
 };
 
 static void transform_destroy(void *self)
@@ -55,6 +84,7 @@ static void transform_destroy(void *self)
     coolmic_transform_t *t = self;
     coolmic_ro_unref(t->io);
     cmhip_batch_free(t->dev);
+    free(t->rec);
     pthread_mutex_destroy(&t->lock);
 }
 
@@ -103,15 +133,84 @@ static void transform_settled(coolmic_transform_t *t, unsigned long gen)
     pthread_mutex_unlock(&t->lock);
 }
 
-/* whole frames through the GPU, in place.  0 on success. */
-static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames)
+/* ---- records mode: the descriptor FIFO ---------------------------------------------------------- */
+
+static transform_record_t *rec_at_index(coolmic_transform_t *t, size_t i)
+{
+    return &t->rec[(t->rec_head + i) % t->rec_cap];
+}
+
+static int rec_push(coolmic_transform_t *t, uint64_t off, uint32_t bytes, uint64_t seq)
+{
+    transform_record_t *r;
+
+    if (t->rec_count == t->rec_cap) {
+        const size_t cap = t->rec_cap ? 2 * t->rec_cap : 64;
+        transform_record_t *grown = malloc(cap * sizeof(*grown));
+        size_t i;
+        if (grown == NULL)
+            return -1;
+        for (i = 0; i < t->rec_count; i++)
+            grown[i] = *rec_at_index(t, i);
+        free(t->rec);
+        t->rec = grown;
+        t->rec_cap = cap;
+        t->rec_head = 0;
+    }
+    r = rec_at_index(t, t->rec_count++);
+    r->off = off;
+    r->bytes = bytes;
+    r->seq = seq;
+    r->have = 0;
+    return 0;
+}
+
+/* every window that is still only on the device comes to its descriptor (one copy for all of them); the
+ * ring slots are cleared for their next turn */
+static int rec_fetch_all(coolmic_transform_t *t)
+{
+    const uint64_t next = cmhip_batch_vu_ring_seq(t->dev);
+    const unsigned int count = (unsigned int)(next - t->rec_fetched_seq);
+    cmhip_vu_raw_t *tmp;
+    size_t i;
+
+    if (count == 0)
+        return 0;
+    tmp = malloc(count * sizeof(*tmp));
+    if (tmp == NULL || cmhip_batch_vu_ring_fetch(t->dev, t->rec_fetched_seq, count, tmp) != COOLMIC_ERROR_NONE) {
+        free(tmp);
+        return -1;
+    }
+    for (i = t->rec_count; i-- > 0;) {           /* newest first: the unfetched ones are at the end */
+        transform_record_t *r = rec_at_index(t, i);
+        if (r->seq < t->rec_fetched_seq)
+            break;
+        r->raw = tmp[r->seq - t->rec_fetched_seq];
+        r->have = 1;
+    }
+    free(tmp);
+    t->rec_fetched_seq = next;
+    return 0;
+}
+
+static void rec_drop_front(coolmic_transform_t *t, size_t n)
+{
+    t->rec_head = (t->rec_head + n) % (t->rec_cap ? t->rec_cap : 1);
+    t->rec_count -= n;
+    t->rec_dropped += n;
+    if (t->rec_cursor < t->rec_dropped)
+        t->rec_cursor = t->rec_dropped;
+}
+
+/* whole frames through the GPU, in place.  `off`: where these bytes lie in the handle's output.  0 on success. */
+static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames, uint64_t off)
 {
     uint16_t scale, gain[COOLMIC_DSP_TRANSFORM_MAX_CHANNELS];
     uint8_t chmap[COOLMIC_DSP_TRANSFORM_MAX_CHANNELS];
     float eq_coef[5 * COOLMIC_DSP_TRANSFORM_MAX_EQ_SECTIONS];
     unsigned int eq_sections;
     unsigned long gen;
-    int identity, dirty, eq_clear, idle;
+    int identity, dirty, eq_clear, idle, vu_mode, vu_on, vu_reset;
 
     pthread_mutex_lock(&t->lock);
     scale = t->scale;
@@ -123,18 +222,23 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
     eq_clear = t->eq_clear;
     dirty = t->dirty;
     gen = t->gen;
+    vu_mode = t->vu_mode;
+    vu_on = vu_mode == VU_RECORDS || (vu_mode == VU_DIRECT && t->vu_armed);
+    vu_reset = t->vu_reset_pending;
+    if (t->dev != NULL)
+        t->vu_reset_pending = 0;       /* done below; without a device there is no window yet */
     pthread_mutex_unlock(&t->lock);
 
     /* nothing to do, exactly as the reference (ref: src/transform.c:107-108) -- but a device
      * that exists must still hear about it: "equaliser off" also clears the filter state, and
      * a later set_eq() must not filter on from what the old one left behind */
-    idle = scale == 0 && identity && eq_sections == 0 && !(t->fused_vu && t->vu_armed);
+    idle = scale == 0 && identity && eq_sections == 0 && !vu_on;
     if (idle && t->dev == NULL) {
         if (dirty || eq_clear)         /* a batch made later starts from zero state and uploads everything */
             transform_settled(t, gen);
         return 0;
     }
-    if (idle && !dirty && !eq_clear)
+    if (idle && !dirty && !eq_clear && !vu_reset)
         return 0;
 
     if (t->dev == NULL) {
@@ -156,6 +260,21 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
             return -1;
         }
         dirty = 1;
+        pthread_mutex_lock(&t->lock);
+        t->vu_reset_pending = 0;       /* a new batch's window is empty */
+        pthread_mutex_unlock(&t->lock);
+        vu_reset = 0;
+    }
+    if (vu_reset && cmhip_batch_vu_reset(t->dev, 0) != COOLMIC_ERROR_NONE)
+        return -1;
+    /* the batch follows the mode: a window ring for the records, the one window otherwise */
+    if ((vu_mode == VU_RECORDS) != (t->ring_on != 0)) {
+        if (cmhip_batch_vu_ring(t->dev, vu_mode == VU_RECORDS ? TRANSFORM_RING_SLOTS : 0) != COOLMIC_ERROR_NONE) {
+            coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_GENERIC, "window ring: %s", cmhip_last_error());
+            return -1;
+        }
+        t->ring_on = vu_mode == VU_RECORDS;
+        t->rec_fetched_seq = cmhip_batch_vu_ring_seq(t->dev);
     }
     if (dirty || eq_clear) {
         int rc = cmhip_batch_set_gain(t->dev, 0, scale ? t->channels : 0, scale, gain);
@@ -174,9 +293,18 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
     }
     if (idle)
         return 0;
-    cmhip_batch_vu_pause(t->dev, !(t->fused_vu && t->vu_armed));
+    cmhip_batch_vu_pause(t->dev, !vu_on);
     while (frames) {
         const size_t n = frames < TRANSFORM_SLICE_FRAMES ? frames : TRANSFORM_SLICE_FRAMES;
+        uint64_t seq = 0;
+        if (vu_mode == VU_RECORDS) {   /* this launch's slot of the ring must have been fetched and cleared */
+            seq = cmhip_batch_vu_ring_seq(t->dev);
+            if (seq - t->rec_fetched_seq >= TRANSFORM_RING_SLOTS && rec_fetch_all(t) != 0) {
+                coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_GENERIC,
+                                    "fetching window records failed: %s", cmhip_last_error());
+                return -1;
+            }
+        }
         if (cmhip_batch_upload(t->dev, 0, pcm, n) != COOLMIC_ERROR_NONE ||
             cmhip_batch_run(t->dev, n, NULL) != COOLMIC_ERROR_NONE ||
             cmhip_batch_download(t->dev, 0, pcm, n) != COOLMIC_ERROR_NONE) {
@@ -184,6 +312,9 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
                                 "HIP transform failed: %s", cmhip_last_error());
             return -1;
         }
+        if (vu_mode == VU_RECORDS && rec_push(t, off, (uint32_t)(n * 2u * t->channels), seq) != 0)
+            return -1;
+        off += n * 2u * t->channels;
         pcm += n * t->channels;
         frames -= n;
     }
@@ -220,8 +351,9 @@ ssize_t coolmic_transform_handle_read(void *userdata, void *buffer, size_t len)
         have -= tail;
     }
 
-    if (have && transform_process(t, buffer, have / framesize) != 0)
+    if (have && transform_process(t, buffer, have / framesize, t->out_bytes) != 0)
         return -1;
+    t->out_bytes += have;
     return (ssize_t)have;
 }
 
@@ -245,24 +377,47 @@ static int transform_handle_free(void *userdata)
  * sees exactly the frames this transform returns (ref: src/simple.c:212-229 wires them through a
  * tee, config 1 of BASELINE.json directly).  Then one launch does both loops of the reference --
  * __process (ref: src/transform.c:101-124) and the accumulate loop (ref: src/vumeter.c:161-177).
- * One meter at a time; the window starts empty. */
+ * One meter at a time; the window starts empty (it is cleared by the next block, on the thread
+ * that reads -- the mode may be switched from another thread while a read is under way). */
 int coolmic_transform_fuse_vu(coolmic_transform_t *self, int on)
 {
+    int rc = COOLMIC_ERROR_NONE;
+
     if (self == NULL)
         return COOLMIC_ERROR_FAULT;
-    if (on && self->fused_vu)
-        return COOLMIC_ERROR_BUSY;
-    self->fused_vu = on ? 1 : 0;
-    self->vu_armed = 0;
-    if (self->dev != NULL && cmhip_batch_vu_reset(self->dev, 0) != COOLMIC_ERROR_NONE)
-        return COOLMIC_ERROR_GENERIC;
-    return COOLMIC_ERROR_NONE;
+    pthread_mutex_lock(&self->lock);
+    if (on && self->vu_mode != VU_NONE) {
+        rc = COOLMIC_ERROR_BUSY;
+    } else if (on || self->vu_mode == VU_DIRECT) {
+        self->vu_mode = on ? VU_DIRECT : VU_NONE;
+        self->vu_armed = 0;
+        self->vu_reset_pending = 1;
+    }
+    pthread_mutex_unlock(&self->lock);
+    return rc;
 }
 
 void coolmic_transform_arm_vu(coolmic_transform_t *self, int armed)
 {
-    if (self != NULL)
-        self->vu_armed = armed ? 1 : 0;
+    if (self == NULL)
+        return;
+    pthread_mutex_lock(&self->lock);
+    self->vu_armed = armed ? 1 : 0;
+    pthread_mutex_unlock(&self->lock);
+}
+
+/* a reset that no block has carried out yet is carried out now (reader's thread) */
+static int transform_vu_settle(coolmic_transform_t *self)
+{
+    int pending;
+
+    pthread_mutex_lock(&self->lock);
+    pending = self->vu_reset_pending;
+    self->vu_reset_pending = 0;
+    pthread_mutex_unlock(&self->lock);
+    if (pending && self->dev != NULL && cmhip_batch_vu_reset(self->dev, 0) != COOLMIC_ERROR_NONE)
+        return COOLMIC_ERROR_GENERIC;
+    return COOLMIC_ERROR_NONE;
 }
 
 int coolmic_transform_vu_result(coolmic_transform_t *self, coolmic_vumeter_result_t *result)
@@ -271,16 +426,130 @@ int coolmic_transform_vu_result(coolmic_transform_t *self, coolmic_vumeter_resul
         return COOLMIC_ERROR_FAULT;
     if (self->dev == NULL)
         return COOLMIC_ERROR_INVAL;    /* no frame has passed yet (ref: src/vumeter.c:198-199) */
+    if (transform_vu_settle(self) != COOLMIC_ERROR_NONE)
+        return COOLMIC_ERROR_GENERIC;
     return cmhip_batch_vu_result(self->dev, 0, result);
+}
+
+/* the window so far, raw, and a fresh one from here (a meter that leaves takes its frames along) */
+int coolmic_transform_vu_take_raw(coolmic_transform_t *self, cmhip_vu_raw_t *raw)
+{
+    if (self == NULL || raw == NULL)
+        return COOLMIC_ERROR_FAULT;
+    if (self->dev == NULL)
+        return COOLMIC_ERROR_INVAL;
+    if (transform_vu_settle(self) != COOLMIC_ERROR_NONE ||
+        cmhip_batch_vu_raw_state(self->dev, 0, raw) != COOLMIC_ERROR_NONE ||
+        cmhip_batch_vu_reset(self->dev, 0) != COOLMIC_ERROR_NONE)
+        return COOLMIC_ERROR_GENERIC;
+    return COOLMIC_ERROR_NONE;
 }
 
 int coolmic_transform_vu_reset(coolmic_transform_t *self)
 {
     if (self == NULL)
         return COOLMIC_ERROR_FAULT;
-    if (self->dev != NULL && cmhip_batch_vu_reset(self->dev, 0) != COOLMIC_ERROR_NONE)
-        return COOLMIC_ERROR_GENERIC;
+    pthread_mutex_lock(&self->lock);
+    self->vu_reset_pending = 1;
+    pthread_mutex_unlock(&self->lock);
+    return transform_vu_settle(self);
+}
+
+/* ---- window records for a meter behind a tee (internal: vumeter.c) ----------------------------- */
+
+/* on: every launch from now on leaves a record {bytes it covered, its own VU window}.  The windows stay
+ * on the device, in a ring, until somebody needs their values (coolmic_transform_records_merge, or the
+ * ring coming round): a pull costs no more than it does for the direct meter. */
+int coolmic_transform_records(coolmic_transform_t *self, int on)
+{
+    int rc = COOLMIC_ERROR_NONE;
+
+    if (self == NULL)
+        return COOLMIC_ERROR_FAULT;
+    pthread_mutex_lock(&self->lock);
+    if (on && self->vu_mode != VU_NONE)
+        rc = COOLMIC_ERROR_BUSY;
+    else if (on)
+        self->vu_mode = VU_RECORDS;
+    else if (self->vu_mode == VU_RECORDS)
+        self->vu_mode = VU_NONE;
+    pthread_mutex_unlock(&self->lock);
+    if (rc == COOLMIC_ERROR_NONE) {
+        self->rec_start = self->out_bytes;
+        rec_drop_front(self, self->rec_count);
+    }
+    return rc;
+}
+
+uint64_t coolmic_transform_out_bytes(const coolmic_transform_t *self)
+{
+    return self->out_bytes;
+}
+
+uint64_t coolmic_transform_records_start(const coolmic_transform_t *self)
+{
+    return self->rec_start;
+}
+
+/* the record that covers byte `pos` of the output */
+int coolmic_transform_record_at(coolmic_transform_t *self, uint64_t pos, uint64_t *off, uint32_t *bytes)
+{
+    size_t i = self->rec_cursor >= self->rec_dropped ? (size_t)(self->rec_cursor - self->rec_dropped) : 0;
+
+    if (i >= self->rec_count || rec_at_index(self, i)->off > pos)
+        i = 0;
+    for (; i < self->rec_count; i++) {
+        const transform_record_t *r = rec_at_index(self, i);
+        if (pos < r->off)
+            break;
+        if (pos < r->off + r->bytes) {
+            self->rec_cursor = self->rec_dropped + i;
+            *off = r->off;
+            *bytes = r->bytes;
+            return COOLMIC_ERROR_NONE;
+        }
+    }
+    return COOLMIC_ERROR_INVAL;
+}
+
+/* merges, oldest first, the records that lie wholly inside [from, to) into `acc` and drops them together
+ * with everything older.  Records inside the range must be contiguous from `from` (they are, for bytes
+ * that came out of this handle one after the other); COOLMIC_ERROR_INVAL if one is missing. */
+int coolmic_transform_records_merge(coolmic_transform_t *self, uint64_t from, uint64_t to, cmhip_vu_raw_t *acc)
+{
+    size_t i, n = 0;
+    uint64_t at = from;
+
+    for (i = 0; i < self->rec_count; i++) {
+        transform_record_t *r = rec_at_index(self, i);
+        if (r->off + r->bytes <= from) {            /* older than the range: consumed in pieces, or skipped */
+            n = i + 1;
+            continue;
+        }
+        if (r->off < from || r->off + r->bytes > to)
+            break;
+        if (r->off != at)
+            return COOLMIC_ERROR_INVAL;
+        if (!r->have && (self->dev == NULL || rec_fetch_all(self) != 0 || !r->have))
+            return COOLMIC_ERROR_GENERIC;
+        cmhip_vu_raw_merge(acc, &r->raw, self->channels);
+        at = r->off + r->bytes;
+        n = i + 1;
+    }
+    if (at != to && !(from == to))
+        return COOLMIC_ERROR_INVAL;                 /* the range does not end on a record boundary */
+    rec_drop_front(self, n);
     return COOLMIC_ERROR_NONE;
+}
+
+/* drops the records that end at or before `upto` (their bytes will not be asked for) */
+void coolmic_transform_records_drop(coolmic_transform_t *self, uint64_t upto)
+{
+    size_t n = 0;
+
+    while (n < self->rec_count && rec_at_index(self, n)->off + rec_at_index(self, n)->bytes <= upto)
+        n++;
+    rec_drop_front(self, n);
 }
 
 void coolmic_transform_format(const coolmic_transform_t *self, uint_least32_t *rate, unsigned int *channels)

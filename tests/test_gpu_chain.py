@@ -131,18 +131,15 @@ def test_chain_matches_oracle_on_noise_with_map(gpu, oracle):
         o.unref()
 
 
-def test_product_wiring_with_tee(gpu, oracle):
-    """snddev -> transform -> tee -> {encoder branch, vumeter}, as ref: src/simple.c:183-236
-    wires it; the encoder branch is played by a reader pulling 1024 bytes at a time
-    (ref: src/enc_vorbis.c:91)."""
-    cm = gpu
-    C, frames = 2, 30000
-    x = oracle.lcg(77, frames * C)
-    src = cm.IoHandle.from_bytes(x.tobytes(), chunk=4096)
+def _tee_chain(cm, x, C, chunk=4096, gain=(2, 1000, [750, 1250])):
+    """source -> transform -> tee -> {reader 0 (the encoder branch), vumeter on reader 1}, in the order
+    ref: src/simple.c:212-229 attaches them"""
+    src = cm.IoHandle.from_bytes(x.tobytes(), chunk=chunk)
     tr = cm.Transform(48000, C)
     assert tr.attach(src) == 0
     src.unref()
-    assert tr.set_master_gain(2, 1000, [750, 1250]) == 0
+    if gain:
+        assert tr.set_master_gain(*gain) == 0
     tee = cm.Tee(2)
     h = tr.get_iohandle()
     assert tee.attach(h) == 0
@@ -152,22 +149,222 @@ def test_product_wiring_with_tee(gpu, oracle):
     h = tee.get_iohandle(1)
     assert vu.attach(h) == 0
     h.unref()
+    return tr, tee, enc_in, vu
+
+
+def test_product_wiring_with_tee(gpu, oracle):
+    """snddev -> transform -> tee -> {encoder branch, vumeter}, as ref: src/simple.c:183-236
+    wires it; the encoder branch is played by a reader pulling 1024 bytes at a time
+    (ref: src/enc_vorbis.c:91).  The meter behind the tee shares the transform's launches (window
+    records, vumeter.c): ONE launch per 1024-byte pull for both branches, results as the oracle's, a
+    result every 20 reads as the product takes them (ref: src/simple.c:370,486-491)."""
+    cm = gpu
+    C, frames = 2, 30000
+    x = oracle.lcg(77, frames * C)
+    tr, tee, enc_in, vu = _tee_chain(cm, x, C)
+    assert vu.mode() == 2                                  # through the tee, by records
+    _, g = oracle.gain(C, 2, 1000, [750, 1250])
+    want = oracle.gain_apply(g, x, C)
     pcm = b""
+    runs0 = cm.lib.cmhip_debug_run_count()
+    pulls = reads = seen = 0
+    v = oracle.vu_new(C)
     for _ in range(100000):
         n, d = enc_in.read(1024)
         pcm += d
+        pulls += 1 if n > 0 else 0
         m = vu.read(-1)
+        if m > 0:
+            oracle.vu_accumulate(v, want[seen // 2: (seen + m) // 2])
+            seen += m
+            reads += 1
+            if reads % 20 == 0:
+                rc, r = vu.result()
+                _, ro = oracle.vu_result(v)
+                assert rc == 0 and r.as_dict() == of.vu_result_dict(ro), reads
+                v = oracle.vu_new(C)
         if n == 0 and m <= 0 and enc_in.eof() == 1:
             break
-    _, g = oracle.gain(C, 2, 1000, [750, 1250])
-    want = oracle.gain_apply(g, x, C)
     assert np.array_equal(np.frombuffer(pcm, np.int16), want)
+    assert seen == x.nbytes and vu.mode() == 2
+    # both branches served by the transform's launches alone: one per pull of the tee, none of the meter's
+    assert cm.lib.cmhip_debug_run_count() - runs0 == pulls
     rc, r = vu.result()
-    v = oracle.vu_new(C)
-    oracle.vu_accumulate(v, want)
     _, ro = oracle.vu_result(v)
     assert rc == 0 and r.as_dict() == of.vu_result_dict(ro)
+    assert vu.result()[0] == cm.ERROR_INVAL
     for o in (enc_in, vu, tee, tr):
+        o.unref()
+
+
+@pytest.mark.parametrize("who_leads", ["encoder", "meter", "mixed"])
+def test_meter_behind_a_tee_lags_and_cuts_blocks(gpu, oracle, who_leads):
+    """The meter's reads do not line up with the transform's launches: the encoder branch pulls odd sizes
+    and runs up to the tee's 8 KiB ahead (or the meter leads and its 1024-byte reads drive the launches),
+    result() and reset() fall inside launches' blocks, reads of a few bytes leave partial frames in the
+    meter's buffer.  Every window against the oracle's, whatever mixture of whole records and cut blocks
+    it was put together from."""
+    cm = gpu
+    C, frames = 2, 40000
+    x = oracle.lcg(123, frames * C)
+    tr, tee, enc_in, vu = _tee_chain(cm, x, C, chunk=3000, gain=(2, 1000, [1250, 600]))
+    assert vu.mode() == 2
+    _, g = oracle.gain(C, 2, 1000, [1250, 600])
+    want = oracle.gain_apply(g, x, C)
+    rng = np.random.default_rng({"encoder": 1, "meter": 2, "mixed": 3}[who_leads])
+    enc_sizes = [1024, 4096, 300, 8192, 20, 2048]
+    vu_sizes = [-1, -1, 7, 500, -1, 3, 1000, -1]
+    enc_got = vu_got = 0            # bytes each branch has taken
+    acc = 0                         # meter bytes accounted (whole frames) in v
+    v = oracle.vu_new(C)
+    pcm = b""
+    step = 0
+    windows = cuts = 0
+    while True:
+        step += 1
+        lead = who_leads if who_leads != "mixed" else ("encoder" if (step // 7) % 2 else "meter")
+        n = m = 0
+        if lead == "encoder" or step % 3 == 0:
+            n, d = enc_in.read(enc_sizes[step % len(enc_sizes)])
+            pcm += d
+            enc_got += max(n, 0)
+        k = 1 if lead == "encoder" else 3
+        for i in range(k):
+            m = vu.read(vu_sizes[(step + i) % len(vu_sizes)])
+            assert m >= 0
+            vu_got += m
+        whole = vu_got - vu_got % (2 * C)          # the meter accounts whole frames, keeps the rest
+        if whole > acc:
+            oracle.vu_accumulate(v, want[acc // 2: whole // 2])
+            acc = whole
+        r_ = rng.random()
+        if r_ < 0.12:
+            rc, r = vu.result()
+            rc_o, ro = oracle.vu_result(v)
+            assert rc == rc_o, (step, rc, rc_o)
+            if rc == 0:
+                assert r.as_dict() == of.vu_result_dict(ro), (step, who_leads)
+                windows += 1
+            v = oracle.vu_new(C)
+        elif r_ < 0.16:
+            assert vu.reset() == 0
+            v = oracle.vu_new(C)
+            cuts += 1
+        if enc_got >= x.nbytes and vu_got >= x.nbytes:
+            break
+        if step > 20000:
+            raise AssertionError("no progress")
+        if lead == "meter" and enc_got + 8192 < vu_got:   # the tee holds 8 KiB for the slower reader
+            n, d = enc_in.read(4096)
+            pcm += d
+            enc_got += max(n, 0)
+    assert vu.mode() == 2 and windows > 10 and cuts > 2
+    while enc_got < x.nbytes:
+        n, d = enc_in.read(4096)
+        assert n > 0
+        pcm += d
+        enc_got += n
+    assert np.array_equal(np.frombuffer(pcm, np.int16), want)
+    rc, r = vu.result()
+    rc_o, ro = oracle.vu_result(v)
+    assert rc == rc_o and (rc != 0 or r.as_dict() == of.vu_result_dict(ro))
+    for o in (enc_in, vu, tee, tr):
+        o.unref()
+
+
+def test_meter_joins_a_running_tee_and_survives_a_second_reader_of_the_transform(gpu, oracle):
+    """(a) The meter is attached when the encoder branch has already pulled for a while and the tee holds
+    bytes no record covers: they go through a launch of the meter's own, the rest by records.  (b) Then
+    somebody reads the transform's handle past the tee: the tee's bytes no longer continue the transform's
+    output, the meter notices and goes back to a batch of its own without losing a frame of its window.
+    (c) A tee whose transform is attached after the meter got the tee's handle is looked at again at the
+    first read."""
+    cm = gpu
+    C, frames = 1, 30000
+    x = oracle.lcg(9, frames * C)
+    src = cm.IoHandle.from_bytes(x.tobytes(), chunk=2000)
+    tr = cm.Transform(48000, C)
+    assert tr.attach(src) == 0
+    src.unref()
+    assert tr.set_master_gain(1, 1000, [800]) == 0
+    _, g = oracle.gain(C, 1, 1000, [800])
+    want = oracle.gain_apply(g, x, C)
+    tee = cm.Tee(2)
+    th = tr.get_iohandle()
+    assert tee.attach(th) == 0
+    enc_in = tee.get_iohandle(0)
+    pos_e = 0
+    for _ in range(3):                                   # 3 KiB in the tee before any meter exists
+        n, d = enc_in.read(1024)
+        assert n == 1024 and np.array_equal(np.frombuffer(d, np.int16), want[pos_e // 2: (pos_e + n) // 2])
+        pos_e += n
+    vu = cm.Vumeter(48000, C)
+    h = tee.get_iohandle(1)
+    assert vu.attach(h) == 0
+    h.unref()
+    assert vu.mode() == 2
+    v = oracle.vu_new(C)
+    pos_v = 0
+    for i in range(12):
+        if i % 2:
+            n, d = enc_in.read(1024)
+            pos_e += n
+        m = vu.read(-1)
+        assert m > 0
+        oracle.vu_accumulate(v, want[pos_v // 2: (pos_v + m) // 2])
+        pos_v += m
+    rc, r = vu.result()
+    _, ro = oracle.vu_result(v)
+    assert rc == 0 and r.as_dict() == of.vu_result_dict(ro)
+    # (b) a second consumer of the transform's own handle: the bytes it takes never reach the tee
+    v = oracle.vu_new(C)
+    stream = max(pos_e, pos_v)                           # what the transform has produced = what the tee pulled
+    for i in range(4):
+        m = vu.read(-1)
+        oracle.vu_accumulate(v, want[pos_v // 2: (pos_v + m) // 2])
+        pos_v += m
+    stream = max(stream, pos_v)
+    n, d = th.read(600)
+    assert n == 600 and np.array_equal(np.frombuffer(d, np.int16), want[stream // 2: stream // 2 + 300])
+    # from here the tee's stream is the transform's output without those 600 bytes
+    rest = np.concatenate([want[: stream // 2], want[stream // 2 + 300:]])
+    for i in range(10):
+        m = vu.read(-1)
+        assert m > 0
+        oracle.vu_accumulate(v, rest[pos_v // 2: (pos_v + m) // 2])
+        pos_v += m
+    assert vu.mode() == 0                                # noticed, and back on a batch of its own
+    rc, r = vu.result()
+    _, ro = oracle.vu_result(v)
+    assert rc == 0 and r.as_dict() == of.vu_result_dict(ro)
+    for o in (th, enc_in, vu, tee, tr):
+        o.unref()
+    # (c) meter first, transform under the tee later
+    y = oracle.lcg(10, 4000)
+    tee = cm.Tee(2)
+    vu = cm.Vumeter(48000, 1)
+    h = tee.get_iohandle(1)
+    assert vu.attach(h) == 0 and vu.mode() == 0
+    h.unref()
+    src = cm.IoHandle.from_bytes(y.tobytes())
+    tr = cm.Transform(48000, 1)
+    assert tr.attach(src) == 0 and tr.set_master_gain(1, 2, [1]) == 0
+    src.unref()
+    th = tr.get_iohandle()
+    assert tee.attach(th) == 0
+    th.unref()
+    v = oracle.vu_new(1)
+    while True:
+        m = vu.read(-1)
+        if m <= 0:
+            break
+        assert vu.mode() == 2
+    _, g = oracle.gain(1, 1, 2, [1])
+    oracle.vu_accumulate(v, oracle.gain_apply(g, y, 1))
+    rc, r = vu.result()
+    _, ro = oracle.vu_result(v)
+    assert rc == 0 and r.as_dict() == of.vu_result_dict(ro)
+    for o in (vu, tee, tr):
         o.unref()
 
 
