@@ -142,6 +142,11 @@ struct cmhip_batch {
     int16_t *d_in, *d_out;
     int16_t *h_in, *h_out;         // CMHIP_HOSTPCM: the slots live in pinned host memory (d_* alias them)
     bool in_flight;                // a launch may still be using the slots (CMHIP_HOSTPCM)
+    // CMHIP_HOSTPCM: a launch of one workgroup reports its end through a word in pinned, device-mapped host
+    // memory (RunArgs::done_flag) and the host spins on it -- 4-5 us less per pull than waiting for the stream
+    uint32_t *h_done, *d_done;
+    uint32_t done_seq;             // the last sequence number handed to a launch
+    bool done_flagged;             // ... and that launch carries the flag
     float *d_f32;
     StreamParam *d_param;
     VuState *d_vu;                         // the window runs accumulate into (= d_vu2[cur])
@@ -308,6 +313,8 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     for (int i = 0; i < 2; i++)
         if (b->snap_event2[i])
             (void)hipEventDestroy(b->snap_event2[i]);
+    if (b->h_done)
+        (void)hipHostFree(b->h_done);
     if (b->d.flags & CMHIP_HOSTPCM) {
         if (b->h_out && b->h_out != b->h_in)
             (void)hipHostFree(b->h_out);
@@ -592,6 +599,11 @@ static int batch_init(cmhip_batch_t *b)
         HIP_TRY(hipHostMalloc((void **)&b->h_in, pcm_bytes, hipHostMallocMapped));
         memset(b->h_in, 0, pcm_bytes);
         HIP_TRY(hipHostGetDevicePointer((void **)&b->d_in, b->h_in, 0));
+        if (!getenv("CMHIP_NO_DONE_FLAG")) {             // (A/B knob)
+            HIP_TRY(hipHostMalloc((void **)&b->h_done, 64, hipHostMallocMapped));
+            memset(b->h_done, 0, 64);
+            HIP_TRY(hipHostGetDevicePointer((void **)&b->d_done, b->h_done, 0));
+        }
         if ((d.flags & CMHIP_OUT_PCM) && !(d.flags & CMHIP_INPLACE)) {
             HIP_TRY(hipHostMalloc((void **)&b->h_out, pcm_bytes, hipHostMallocMapped));
             memset(b->h_out, 0, pcm_bytes);
@@ -707,6 +719,9 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->d_in = b->d_out = nullptr;
     b->h_in = b->h_out = nullptr;
     b->in_flight = false;
+    b->h_done = b->d_done = nullptr;
+    b->done_seq = 0;
+    b->done_flagged = false;
     b->d_f32 = nullptr;
     b->d_param = nullptr;
     b->d_gshort = nullptr;
@@ -949,8 +964,22 @@ extern "C" void *cmhip_batch_hip_stream(cmhip_batch_t *b) { return b ? (void *)b
 static int host_slots_quiet(cmhip_batch_t *b)
 {
     if (b->in_flight) {
-        HIP_TRY(hipStreamSynchronize(b->stream));
+        bool done = false;
+        if (b->done_flagged) {
+            // the launch's own last act was to store its sequence number here (done_epilogue): a bounded
+            // spin, then the stream after all (a kernel that faulted never stores)
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+            unsigned spins = 0;
+            while (!(done = __atomic_load_n(b->h_done, __ATOMIC_ACQUIRE) == b->done_seq)) {
+                if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() > t_end)
+                    break;
+                __builtin_ia32_pause();
+            }
+        }
+        if (!done)
+            HIP_TRY(hipStreamSynchronize(b->stream));
         b->in_flight = false;
+        b->done_flagged = false;
     }
     return COOLMIC_ERROR_NONE;
 }
@@ -1160,6 +1189,7 @@ extern "C" int cmhip_batch_generate(cmhip_batch_t *b, int mode, uint32_t seed, s
         return fail(COOLMIC_ERROR_GENERIC, "generate: sine table unavailable");
     HIP_TRY(launch_generate(g, mode, b->stream));
     b->in_flight = true;
+    b->done_flagged = false;               // (whatever run went before: this kernel is behind it and carries no flag)
     return COOLMIC_ERROR_NONE;
 }
 
@@ -1274,11 +1304,18 @@ static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per
     const bool timed = b->timing && b->timing_count++ % b->timing_every == 0;
     if (timed) {
         ev = take_events(b);
-    } else if (vu) {                         // the end of this run, for the next snapshot
+    } else if (vu && !b->h_in) {             // the end of this run, for the next snapshot
+        // (not for slots in host memory: those batches are fed block by block and waited for, and the stop
+        // event costs a launch 2 us -- tools/ubench_roundtrip.hip; a snapshot records an event of its own then)
         ev.b = b->ev_done[b->done_next];
         b->done_next = (b->done_next + 1u) & 3u;
     }
     b->last_done = vu ? ev.b : nullptr;
+    // completion by flag: only where the host waits for every launch (CMHIP_HOSTPCM), every stream runs
+    // its whole count, and -- the launcher decides -- the grid is one workgroup
+    uint32_t *const flag = (b->d_done && !frames_per_stream) ? b->d_done : nullptr;
+    const uint32_t flag_seq = ++b->done_seq;
+    bool flagged = false;
     if ((b->d.flags & CMHIP_EQ) && b->nsec) {        // without sections the plain kernels do the same
         EqArgs a;
         memset(&a, 0, sizeof(a));
@@ -1299,7 +1336,9 @@ static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per
         a.dbg = b->d_dbg;
         a.stride = b->stride;
         a.plane = b->plane;
-        HIP_TRY(launch_eq(a, b->stream, ev.a, ev.b));
+        a.done_flag = flag;
+        a.done_seq = flag_seq;
+        HIP_TRY(launch_eq(a, b->stream, ev.a, ev.b, &flagged));
         b->in_flight = true;
     } else {
         RunArgs a;
@@ -1320,9 +1359,12 @@ static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per
         a.identity_maps = b->all_identity ? 1u : 0u;
         a.identity_gains = b->all_gain_identity ? 1u : 0u;
         a.parity = parity;
-        HIP_TRY(launch_run(a, b->tune, b->stream, ev.a, ev.b));
+        a.done_flag = flag;
+        a.done_seq = flag_seq;
+        HIP_TRY(launch_run(a, b->tune, b->stream, ev.a, ev.b, &flagged));
         b->in_flight = true;
     }
+    b->done_flagged = flagged;
     if (timed)
         b->ev_used.push_back(ev);
     g_runs.fetch_add(1, std::memory_order_relaxed);

@@ -14,6 +14,18 @@ using u64 = unsigned long long;
 
 __device__ __forceinline__ u32 uniform(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Completion by flag (RunArgs::done_flag; launches of one workgroup only): every wave's stores are made
+// visible at system scope, the workgroup meets, one lane stores the sequence number for the host.
+__device__ __forceinline__ void done_epilogue(uint32_t *flag, uint32_t seq)
+{
+    if (flag) {                                  // (uniform: a kernel argument)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __device__ __forceinline__ u64 make_key(u32 mag, u64 index, u32 neg)
 {
     if (mag == 0)

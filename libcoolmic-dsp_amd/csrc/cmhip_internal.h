@@ -83,6 +83,13 @@ struct RunArgs {
     uint32_t       parity;         // which VuState::samples slot is current
     uint32_t       identity_maps;  // 1 when no stream of the batch has a channel map
     uint32_t       identity_gains; // 1 when no stream of the batch has a gain (disabled or unity everywhere)
+    // Completion by flag, for launches of ONE workgroup (the 1 KiB pulls of the per-stream stages): when not
+    // null the workgroup, at its very end, makes its stores visible to the host and stores done_seq there
+    // (pinned, device-mapped host memory).  The host spins on the word instead of waiting for the stream:
+    // 4-5 us less per launch-and-wait on MI355X (tools/ubench_roundtrip.hip).  The launcher clears it
+    // when the grid has more than one workgroup.
+    uint32_t      *done_flag;
+    uint32_t       done_seq;
 };
 
 // Tuning knobs of the block kernels' launcher, read from the environment ONCE, when a batch is
@@ -116,6 +123,8 @@ struct EqArgs {
     uint64_t       stride;
     uint64_t       plane;
     unsigned long long *dbg;       // 64 words for in-kernel stamps (diagnostic builds only)
+    uint32_t      *done_flag;      // as RunArgs::done_flag
+    uint32_t       done_seq;
 };
 
 struct GenArgs {
@@ -130,12 +139,14 @@ struct GenArgs {
 // launchers (k_block.hip, k_eq.hip, k_misc.hip)
 // (ev_start / ev_stop: optional events that take the kernel's own start and end -- hipExtLaunchKernelGGL
 // stamps them from the dispatch itself, without the extra packets of hipEventRecord around the launch)
+// (*flagged: the launch was one workgroup and carries the completion flag of RunArgs::done_flag)
 hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hipEvent_t ev_start = nullptr,
-                      hipEvent_t ev_stop = nullptr);
+                      hipEvent_t ev_stop = nullptr, bool *flagged = nullptr);
 // (the first launch of an EQ kernel variant on a device raises its dynamic-LDS limit there:
 // prepare_eq does that for a batch's device when the batch is created, launch_eq checks it)
 hipError_t prepare_eq(int device);
-hipError_t launch_eq(const EqArgs &a, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+hipError_t launch_eq(const EqArgs &a, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                     bool *flagged = nullptr);
 hipError_t launch_generate(const GenArgs &a, int mode, hipStream_t st);
 hipError_t launch_node_partial(const VuState *vu, uint32_t streams, uint32_t channels,
                                uint32_t parity, uint64_t first_global, uint64_t global_step,

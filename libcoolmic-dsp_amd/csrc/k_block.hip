@@ -348,6 +348,7 @@ template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U, int NW = 1>
 __global__ __launch_bounds__(64 * NW) void k_run_fast(RunArgs a)
 {
     run_fast<C, WRITE_PCM, WRITE_F32, DO_VU, U, NW>(a);
+    done_epilogue(a.done_flag, a.done_seq);
 }
 // The read-only entry (VU window, no PCM, no floats): at least three waves per SIMD -- the 16 KiB
 // tile holds 128 VGPRs of samples and magnitudes, and with the three arithmetic forms in one
@@ -356,6 +357,7 @@ template <int C, int U>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_run_fast_ro(RunArgs a)
 {
     run_fast<C, false, false, true, U>(a);
+    done_epilogue(a.done_flag, a.done_seq);
 }
 
 // ---------------------------------------------------------------------------
@@ -393,8 +395,10 @@ __global__ __launch_bounds__(64) void k_run_wide(RunArgs a)
         if (k == 0 && lane == 0)
             vs->samples[a.parity ^ 1u] = base + nsamp;
     }
-    if (v0 >= nfull + (ntail ? 1u : 0u))
+    if (v0 >= nfull + (ntail ? 1u : 0u)) {
+        done_epilogue(a.done_flag, a.done_seq);
         return;
+    }
 
     const StreamParam *p = a.param + s;
     const u32 magic = p->magic, shift = p->shift;
@@ -552,6 +556,7 @@ __global__ __launch_bounds__(64) void k_run_wide(RunArgs a)
             }
         }
     }
+    done_epilogue(a.done_flag, a.done_seq);
 }
 
 // ---------------------------------------------------------------------------
@@ -638,8 +643,10 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
         if (k == 0 && lane == 0)
             vs->samples[a.parity ^ 1u] = base + nsamp;
     }
-    if ((u64)row0 * W >= nvec)
+    if ((u64)row0 * W >= nvec) {
+        done_epilogue(a.done_flag, a.done_seq);
         return;
+    }
     if constexpr (DO_VU) {
         if (lane < MAX_CH) {
             lsum[lane] = 0;
@@ -919,6 +926,7 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
                 atomicMax(&vs->key[lane], lkey[lane]);
         }
     }
+    done_epilogue(a.done_flag, a.done_seq);
 }
 
 // ---------------------------------------------------------------------------
@@ -926,11 +934,21 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
 
 constexpr u32 FAST_NW = 4;
 
-hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
+hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop,
+                      bool *flagged)
 {
     const bool pcm = a.out != nullptr, f32 = a.f32 != nullptr, vu = a.vu != nullptr;
+    if (flagged)
+        *flagged = false;
     if (a.streams == 0 || a.frames == 0)
         return hipSuccess;
+    // completion by flag only for a launch of one workgroup (RunArgs::done_flag)
+    auto flag_if_single = [&](RunArgs &b, u32 workgroups) {
+        if (workgroups != 1u)
+            b.done_flag = nullptr;
+        if (flagged)
+            *flagged = b.done_flag != nullptr;
+    };
     if (a.channels <= 2) {
         // one wave per tile: 4 KiB when PCM or float is written, larger read-only
         RunArgs b = a;
@@ -958,6 +976,7 @@ hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hip
         const u32 gridw = a.streams * ((b.chunks + nw - 1u) / nw);
         if ((u64)a.streams * ((b.chunks + nw - 1u) / nw) >= (1ull << 31))
             return hipErrorInvalidValue;
+        flag_if_single(b, (pcm && !f32 && vu && nw > 1u) ? gridw : grid);
 #define CMHIP_FAST(C, P, F, V, U)                                                  \
     hipExtLaunchKernelGGL((k_run_fast<C, P, F, V, U>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b)
 #define CMHIP_FAST_W(C, P, F, V, U)                                                \
@@ -1004,6 +1023,7 @@ hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hip
         if ((u64)b.chunks * a.streams >= (1ull << 31))
             return hipErrorInvalidValue;
         const u32 grid = a.streams * b.chunks;
+        flag_if_single(b, grid);
 #define CMHIP_WIDE(C, P, F, V)                                                     \
     do {                                                                           \
         if (wu == 16u)                                                             \
@@ -1065,6 +1085,7 @@ hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hip
         if ((u64)b.chunks * a.streams >= (1ull << 31))
             return hipErrorInvalidValue;
         const u32 grid = a.streams * b.chunks;
+        flag_if_single(b, grid);
 #define CMHIP_ROWS(P_, F_, V_)                                                                      \
     do {                                                                                            \
         constexpr bool S_ = F_;                        /* staged float planes unless 16 channels */ \

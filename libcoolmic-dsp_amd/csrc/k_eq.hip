@@ -840,6 +840,7 @@ void k_eq_pipe(EqArgs a)
             }
         }
     }
+    done_epilogue(a.done_flag, a.done_seq);
 }
 
 template <int NSEC, int G>
@@ -849,13 +850,18 @@ static constexpr size_t eq_pipe_lds_bytes()
 }
 
 template <int NSEC, int G, int CH>
-static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
+static hipError_t launch_eq_pipe(const EqArgs &a0, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, bool *flagged)
 {
+    EqArgs a = a0;
     constexpr size_t lds_bytes = eq_pipe_lds_bytes<NSEC, G>();
     static_assert(lds_bytes <= 160 * 1024, "tiles of a workgroup must fit the LDS");
     const u64 rows = (u64)a.streams * (CH == 1 ? 1u : a.channels);      // one row per stream and channel
     const u32 spg = CH == 1 ? G : G / a.channels;
     const u32 grid = a.whole_streams ? (a.streams + spg - 1) / spg : (u32)((rows + G - 1) / G);
+    if (grid != 1u)                                      // completion by flag: one workgroup only (EqArgs::done_flag)
+        a.done_flag = nullptr;
+    if (flagged)
+        *flagged = a.done_flag != nullptr;
     hipExtLaunchKernelGGL((k_eq_pipe<NSEC, G, CH>), dim3(grid), dim3(eq_waves<NSEC, G>() * 64), lds_bytes, st, ev_start, ev_stop, 0, a);
     return hipGetLastError();
 }
@@ -863,13 +869,13 @@ static hipError_t launch_eq_pipe(const EqArgs &a, hipStream_t st, hipEvent_t ev_
 // 32 rows per workgroup: all 256 CUs at 8192 mono streams, and what the LDS holds for four
 // sections (8 and 16 rows with several workgroups per CU measured the same or slower)
 template <int NSEC>
-static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
+static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, bool *flagged)
 {
     if (a.channels == 1)
-        return launch_eq_pipe<NSEC, 32, 1>(a, st, ev_start, ev_stop);
+        return launch_eq_pipe<NSEC, 32, 1>(a, st, ev_start, ev_stop, flagged);
     if (a.channels == 2 && a.stride >= 16 && a.stride % 16 == 0)
-        return launch_eq_pipe<NSEC, 32, 2>(a, st, ev_start, ev_stop);
-    return launch_eq_pipe<NSEC, 32, 0>(a, st, ev_start, ev_stop);
+        return launch_eq_pipe<NSEC, 32, 2>(a, st, ev_start, ev_stop, flagged);
+    return launch_eq_pipe<NSEC, 32, 0>(a, st, ev_start, ev_stop, flagged);
 }
 
 // The kernels ask for more dynamic LDS than the default limit; the limit is raised per function
@@ -916,8 +922,10 @@ hipError_t prepare_eq(int device)
     return e;
 }
 
-hipError_t launch_eq(const EqArgs &a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
+hipError_t launch_eq(const EqArgs &a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, bool *flagged)
 {
+    if (flagged)
+        *flagged = false;
     if (a.streams == 0 || a.frames == 0 || !(a.f32 || a.out || a.vu))
         return hipSuccess;
     {
@@ -931,10 +939,10 @@ hipError_t launch_eq(const EqArgs &a, hipStream_t st, hipEvent_t ev_start, hipEv
     if (a.channels == 0 || a.channels > MAX_CH)
         return hipErrorInvalidValue;
     switch (a.nsec) {                                     // (0 sections: the caller uses launch_run)
-    case 1: return launch_eq_pipe_g<1>(a, st, ev_start, ev_stop);            // the pipelined kernel, whatever is asked
-    case 2: return launch_eq_pipe_g<2>(a, st, ev_start, ev_stop);            // for (float planes, int16, VU of it)
-    case 3: return launch_eq_pipe_g<3>(a, st, ev_start, ev_stop);
-    case 4: return launch_eq_pipe_g<4>(a, st, ev_start, ev_stop);
+    case 1: return launch_eq_pipe_g<1>(a, st, ev_start, ev_stop, flagged);            // the pipelined kernel, whatever is asked
+    case 2: return launch_eq_pipe_g<2>(a, st, ev_start, ev_stop, flagged);            // for (float planes, int16, VU of it)
+    case 3: return launch_eq_pipe_g<3>(a, st, ev_start, ev_stop, flagged);
+    case 4: return launch_eq_pipe_g<4>(a, st, ev_start, ev_stop, flagged);
     default: return hipErrorInvalidValue;
     }
 }

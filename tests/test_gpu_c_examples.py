@@ -82,3 +82,32 @@ def test_node_vu_in_c(gpu, oracle, tmp_path):
         s_first = min(range(S), key=lambda s: (frames_of_top[s], s))  # earliest frame, then lowest stream
         peak = int(blk[s_first, frames_of_top[s_first]])
         assert lines[1 + k] == "block %d: frames %d peak %d power %.17g" % (k, S * T, peak, power)
+
+
+def test_product_chain_in_c(gpu, oracle, tmp_path):
+    """The reference's live wiring up to the encoder in plain C (examples/product_chain.c): with and
+    without the tee the meter reports the same last window (20 reads of 512 frames of the sine, at the
+    same place of the stream), which is the oracle's."""
+    pulls = 400
+    lines = _build_and_run(tmp_path, "product_chain", pulls)
+    assert len(lines) == 4
+    rc_s, sine = oracle.sine_table(48000)
+    assert rc_s == 0 and len(sine) == 48
+    for gain_on in (0, 1):
+        direct, tee = lines[2 * gain_on], lines[2 * gain_on + 1]
+        assert direct.startswith("direct gain %s:" % ("on " if gain_on else "off"))
+        assert tee.startswith("tee    gain %s:" % ("on " if gain_on else "off"))
+        assert direct.split("last window:")[1] == tee.split("last window:")[1]
+        assert "frames 10240 " in tee
+    if True:
+        total = (200 + pulls) * 512
+        x = np.tile(np.asarray(sine, dtype=np.int16), total // 48 + 2)[total - 10240: total]
+        for gain_on in (0, 1):
+            y = x
+            if gain_on:
+                _, g = oracle.gain(1, 1, 1000, [900])
+                y = oracle.gain_apply(g, x, 1)
+            v = oracle.vu_new(1)
+            oracle.vu_accumulate(v, y)
+            _, r = oracle.vu_result(v)
+            assert lines[2 * gain_on + 1].endswith("frames 10240 peak %d power %.17g" % (r.global_peak, r.global_power))

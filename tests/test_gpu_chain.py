@@ -246,7 +246,7 @@ def test_meter_behind_a_tee_lags_and_cuts_blocks(gpu, oracle, who_leads):
                 assert r.as_dict() == of.vu_result_dict(ro), (step, who_leads)
                 windows += 1
             v = oracle.vu_new(C)
-        elif r_ < 0.16:
+        elif r_ < 0.20:
             assert vu.reset() == 0
             v = oracle.vu_new(C)
             cuts += 1
@@ -258,7 +258,7 @@ def test_meter_behind_a_tee_lags_and_cuts_blocks(gpu, oracle, who_leads):
             n, d = enc_in.read(4096)
             pcm += d
             enc_got += max(n, 0)
-    assert vu.mode() == 2 and windows > 10 and cuts > 2
+    assert vu.mode() == 2 and windows > 8 and cuts > 1
     while enc_got < x.nbytes:
         n, d = enc_in.read(4096)
         assert n > 0
