@@ -293,11 +293,11 @@ def test_meter_joins_a_running_tee_and_survives_a_second_reader_of_the_transform
     th = tr.get_iohandle()
     assert tee.attach(th) == 0
     enc_in = tee.get_iohandle(0)
-    pos_e = 0
-    for _ in range(3):                                   # 3 KiB in the tee before any meter exists
-        n, d = enc_in.read(1024)
-        assert n == 1024 and np.array_equal(np.frombuffer(d, np.int16), want[pos_e // 2: (pos_e + n) // 2])
-        pos_e += n
+    # 3 KiB in the tee before any meter exists (one read: the tee sizes its buffer by the request and holds
+    # everything for the reader that has not started, ref: src/tee.c:83-135)
+    n, d = enc_in.read(3072)
+    assert n == 3072 and np.array_equal(np.frombuffer(d, np.int16), want[: n // 2])
+    pos_e = n
     vu = cm.Vumeter(48000, C)
     h = tee.get_iohandle(1)
     assert vu.attach(h) == 0
@@ -320,15 +320,17 @@ def test_meter_joins_a_running_tee_and_survives_a_second_reader_of_the_transform
     v = oracle.vu_new(C)
     stream = max(pos_e, pos_v)                           # what the transform has produced = what the tee pulled
     for i in range(4):
+        pos_e += enc_in.read(1024)[0]                    # (the tee stalls a reader that runs its buffer ahead)
         m = vu.read(-1)
         oracle.vu_accumulate(v, want[pos_v // 2: (pos_v + m) // 2])
         pos_v += m
-    stream = max(stream, pos_v)
+    stream = max(stream, pos_v, pos_e)
     n, d = th.read(600)
     assert n == 600 and np.array_equal(np.frombuffer(d, np.int16), want[stream // 2: stream // 2 + 300])
     # from here the tee's stream is the transform's output without those 600 bytes
     rest = np.concatenate([want[: stream // 2], want[stream // 2 + 300:]])
     for i in range(10):
+        pos_e += enc_in.read(1024)[0]
         m = vu.read(-1)
         assert m > 0
         oracle.vu_accumulate(v, rest[pos_v // 2: (pos_v + m) // 2])
@@ -341,9 +343,9 @@ def test_meter_joins_a_running_tee_and_survives_a_second_reader_of_the_transform
         o.unref()
     # (c) meter first, transform under the tee later
     y = oracle.lcg(10, 4000)
-    tee = cm.Tee(2)
+    tee = cm.Tee(1)
     vu = cm.Vumeter(48000, 1)
-    h = tee.get_iohandle(1)
+    h = tee.get_iohandle(0)
     assert vu.attach(h) == 0 and vu.mode() == 0
     h.unref()
     src = cm.IoHandle.from_bytes(y.tobytes())
