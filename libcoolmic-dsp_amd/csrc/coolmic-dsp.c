@@ -27,10 +27,17 @@ const char *coolmic_error2string(const int error)
     return "(unknown)";
 }
 
+/* The stand-alone library names the drivers it brings itself.  Inside the reference's build (`make dropin`,
+ * INTEGRATION.md 3) the drivers and encoders are the host's own: its Makefile passes their tokens in
+ * COOLMIC_HOST_FEATURES (what ref: src/coolmic-dsp.c:64-83 would have put together from its HAVE_* flags),
+ * and this unit adds the one thing it knows: which path computes transform and VU. */
+#ifndef COOLMIC_HOST_FEATURES
+#define COOLMIC_HOST_FEATURES COOLMIC_FEATURE_DRIVER_NULL " " COOLMIC_FEATURE_DRIVER_SINE " " COOLMIC_FEATURE_DRIVER_STDIO
+#endif
+
 const char *coolmic_features(void)
 {
-    return "features " COOLMIC_FEATURE_DRIVER_NULL " " COOLMIC_FEATURE_DRIVER_SINE
-           " " COOLMIC_FEATURE_DRIVER_STDIO " " COOLMIC_FEATURE_ACCEL_HIP;
+    return "features " COOLMIC_HOST_FEATURES " " COOLMIC_FEATURE_ACCEL_HIP;
 }
 
 /* whole-word match inside the space separated list */

@@ -24,6 +24,12 @@ int coolmic_sine_period(uint_least32_t rate, int16_t *table, size_t *samples);
 /* HIP device the per-object (non-batch) stages run on: $COOLMIC_HIP_DEVICE or 0 */
 int coolmic_hip_default_device(void);
 
+/* Everything from here on is glue between the translation units of this library: hidden, not exported. */
+#pragma GCC visibility push(hidden)
+
+ssize_t coolmic_transform_handle_read(void *userdata, void *buffer, size_t len);
+ssize_t coolmic_tee_reader_read(void *userdata, void *buffer, size_t len);
+
 /* A VU meter attached directly to a transform's handle shares the transform's launch (vumeter.c,
  * transform.c): the handle is recognised, the transform accumulates the window, the meter reads it. */
 struct coolmic_transform;
@@ -78,6 +84,8 @@ int coolmic_transform_records(struct coolmic_transform *self, int on);
 uint64_t coolmic_transform_out_bytes(const struct coolmic_transform *self);
 uint64_t coolmic_transform_records_start(const struct coolmic_transform *self);
 int coolmic_transform_record_at(struct coolmic_transform *self, uint64_t pos, uint64_t *off, uint32_t *bytes);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

@@ -70,7 +70,6 @@ int coolmic_iohandle_eof(coolmic_iohandle_t *self)
 }
 
 /* lets a downstream stage of this library recognise a transform's handle */
-extern ssize_t coolmic_transform_handle_read(void *userdata, void *buffer, size_t len);
 struct coolmic_transform *coolmic_iohandle_as_transform(coolmic_iohandle_t *h)
 {
     if (h != NULL && h->read_fn == coolmic_transform_handle_read)
@@ -79,7 +78,6 @@ struct coolmic_transform *coolmic_iohandle_as_transform(coolmic_iohandle_t *h)
 }
 
 /* ... and a tee's reader handle: -> the reader's userdata for coolmic_tee_reader_upstream() */
-extern ssize_t coolmic_tee_reader_read(void *userdata, void *buffer, size_t len);
 void *coolmic_iohandle_as_tee_reader(coolmic_iohandle_t *h)
 {
     if (h != NULL && h->read_fn == coolmic_tee_reader_read)

@@ -95,3 +95,64 @@ def test_no_oracle_in_the_product():
     so = os.path.join(pkg, "lib", "libcoolmic-dsp-hip.so")
     deps = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
     assert "oracle" not in deps
+
+
+REFERENCE = "/root/reference"
+# the translation units the library replaces inside the reference's own build and the
+# reference headers that declare what those units define
+REPLACED_UNITS = {"transform.c": "transform.h", "vumeter.c": "vumeter.h", "iohandle.c": "iohandle.h",
+                  "tee.c": "tee.h", "logging.c": "logging.h", "coolmic-dsp.c": "coolmic-dsp.h"}
+
+
+def _exported(so):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TWB"}
+
+
+def test_dropin_build_exports_what_the_replaced_units_define():
+    """The recipe of INTEGRATION.md 3 takes six translation units out of the reference's build.  Every function
+    the reference's headers declare for those units must come out of `make dropin`
+    (lib/libcoolmic-dsp-hip-dropin.so); what stays the reference's -- the sources snddev*.c with their driver
+    vtable, util.c -- must NOT be defined by it; and the recipe's filter-out list is exactly that set."""
+    import subprocess
+    pkg = os.path.join(ROOT, "libcoolmic-dsp_amd")
+    subprocess.run(["make", "-s", "-C", pkg, "dropin"], check=True)
+    names = _exported(os.path.join(pkg, "lib", "libcoolmic-dsp-hip-dropin.so"))
+    recipe = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"filter-out ([^,]*),", recipe)
+    assert m, "INTEGRATION.md has no filter-out line"
+    assert set(m.group(1).split()) == set(REPLACED_UNITS), m.group(1)
+    kept = {"coolmic_snddev_new", "coolmic_snddev_get_iohandle", "coolmic_snddev_attach_iohandle",
+            "coolmic_snddev_iter", "coolmic_util_ahsv2argb", "coolmic_util_power2hue", "coolmic_util_peak2hue"}
+    assert not (names & kept), names & kept
+    # internal glue between the units is not part of the ABI
+    assert not [n for n in names if n.startswith(("coolmic_transform_records", "coolmic_tee_reader", "cmhip_vu_raw"))]
+    if not os.path.isdir(REFERENCE):
+        pytest.skip("the reference headers are not on this machine; the export list was checked without them")
+    declared = set()
+    for unit, header in REPLACED_UNITS.items():
+        assert os.path.exists(os.path.join(REFERENCE, "src", unit)), unit
+        text = open(os.path.join(REFERENCE, "include", "coolmic-dsp", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"^\s*#\s*define[^\n]*(\\\n[^\n]*)*", "", text, flags=re.M)
+        declared |= {n for n in re.findall(r"\b(coolmic_[a-z0-9_]+)\s*\(", text) if not n.endswith("_t")}
+    assert len(declared) >= 21, sorted(declared)
+    missing = sorted(declared - names)
+    assert not missing, missing
+    # the stand-alone library (with its own sources and helpers) exports them too
+    full = _exported(os.path.join(pkg, "lib", "libcoolmic-dsp-hip.so"))
+    assert not sorted(declared - full)
+
+
+def test_host_feature_tokens_of_the_dropin_build():
+    """inside the reference's build coolmic_features() lists the HOST's encoders and drivers (handed in by its
+    Makefile) plus the token of this path (ref: src/coolmic-dsp.c:64-83)"""
+    import ctypes as C
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "libcoolmic-dsp_amd"), "dropin"], check=True)
+    lib = C.CDLL(os.path.join(ROOT, "libcoolmic-dsp_amd", "lib", "libcoolmic-dsp-hip-dropin.so"))
+    lib.coolmic_features.restype = C.c_char_p
+    toks = lib.coolmic_features().split(b" ")
+    assert toks[0] == b"features" and b"accel:hip/gfx950" in toks and b"encode:ogg/vorbis" in toks
+    assert lib.coolmic_feature_check(b"encode:ogg/opus") == 1 and lib.coolmic_feature_check(b"driver:sine") == 0
