@@ -577,7 +577,10 @@ def main():
         except Exception as e:           # measurement extras must not break the line
             extras["ceiling_error"] = str(e)
         out["measured_ceilings"] = extras
-        # the small-block regime, same batch, fewer frames per launch (kernel only)
+        # the small-block regime, same batch, fewer frames per launch.  Per block size the kernel
+        # alone, the whole STEP with a VU window per block (launch + packed snapshot + host dB finish of all
+        # windows, as in the timed region), and the step when windows close every 20 blocks -- the reference's
+        # own granularity (a result every 20 reads, ref: src/simple.c:370)
         sweep = {}
         try:
             for frames in (512, 2880, 4096):
@@ -593,11 +596,31 @@ def main():
                     b.run(frames)
                 ms, n = b.timing_read()
                 b.timing(False)
-                sweep[str(frames)] = {"kernel_avg_ms": round(ms / n, 4),
-                                      "achieved_GBs": round(S * Cn * frames * bps / (ms / n * 1e-3) / 1e9, 1)}
+                entry = {"kernel_avg_ms": round(ms / n, 4),
+                         "achieved_GBs": round(S * Cn * frames * bps / (ms / n * 1e-3) / 1e9, 1)}
+                for every, key in ((1, "step_ms_window_per_block"), (20, "step_ms_window_per_20_blocks")):
+                    def loop(nsteps):
+                        pending = False
+                        for i in range(nsteps):
+                            b.run(frames)
+                            if i % every == every - 1:
+                                b.vu_snapshot()
+                                if pending:
+                                    b.vu_collect(results, rcs)
+                                pending = True
+                        if pending:
+                            b.vu_collect(results, rcs)
+                        b.sync()
+                    b.vu_reset(-1)
+                    b.sync()
+                    loop(200)
+                    t1 = time.perf_counter()
+                    loop(1000)
+                    entry[key] = round((time.perf_counter() - t1) / 1000 * 1e3, 4)
+                sweep[str(frames)] = entry
         except Exception as e:
             sweep["error"] = str(e)
-        out["small_blocks_kernel_only"] = sweep
+        out["small_blocks"] = sweep
     b.close()
 
     # Several ranks: configs 4 and 5 at this N, outside the timed region and never part of `value` -- the

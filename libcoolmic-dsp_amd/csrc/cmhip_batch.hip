@@ -189,9 +189,10 @@ struct cmhip_batch {
     unsigned int nsec;
     bool eq_dirty;
 
-    VuState *h_snap2[2];                   // pinned, S entries each: two snapshots may be in flight
-    hipEvent_t snap_event2[2];
-    unsigned int snap_parity2[2];
+    // two snapshots may be in flight: each a packed copy of a window set, [1 + 2C][S] words in pinned,
+    // device-mapped host memory that k_vu_pack writes itself (h_pack / d_pack: host / device view)
+    unsigned long long *h_pack[2], *d_pack[2];
+    unsigned int snap_set2[2];             // which of the three window sets the snapshot closed (its event: ev_reset)
     unsigned int snap_head, snap_count;    // ring of pending snapshots (oldest = head)
     unsigned char *h_stage;                // pinned upload ring, STAGE_SLOTS x STAGE_BYTES
     hipEvent_t stage_ev[4];
@@ -310,9 +311,6 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
-    for (int i = 0; i < 2; i++)
-        if (b->snap_event2[i])
-            (void)hipEventDestroy(b->snap_event2[i]);
     if (b->h_done)
         (void)hipHostFree(b->h_done);
     if (b->d.flags & CMHIP_HOSTPCM) {
@@ -355,8 +353,8 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
         (void)hipHostFree(b->h_ring);
     (void)hipFree(b->d_dbg);
     for (int i = 0; i < 2; i++)
-        if (b->h_snap2[i])
-            (void)hipHostFree(b->h_snap2[i]);
+        if (b->h_pack[i])
+            (void)hipHostFree(b->h_pack[i]);
     if (b->h_stage)
         (void)hipHostFree(b->h_stage);
     for (unsigned i = 0; i < STAGE_SLOTS; i++)
@@ -632,7 +630,7 @@ static int batch_init(cmhip_batch_t *b)
     for (int i = 0; i < 3; i++) {
         HIP_TRY(hipMalloc((void **)&b->d_vu2[i], S * sizeof(VuState)));
         HIP_TRY(hipMemsetAsync(b->d_vu2[i], 0, S * sizeof(VuState), b->stream));
-        HIP_TRY(hipEventCreateWithFlags(&b->ev_reset[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreate(&b->ev_reset[i]));       // (stamped by the pack kernel's own dispatch)
     }
     b->d_vu = b->d_vu2[0];
     {
@@ -663,8 +661,9 @@ static int batch_init(cmhip_batch_t *b)
         b->h_eq.assign(S, EqParam{});
     }
     for (int i = 0; i < 2; i++) {
-        HIP_TRY(hipHostMalloc((void **)&b->h_snap2[i], S * sizeof(VuState), hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&b->snap_event2[i], hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void **)&b->h_pack[i], S * (1u + 2u * d.channels) * sizeof(unsigned long long),
+                              hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void **)&b->d_pack[i], b->h_pack[i], 0));
     }
     HIP_TRY(hipHostMalloc((void **)&b->h_stage, STAGE_SLOTS * STAGE_BYTES, hipHostMallocDefault));
     for (unsigned i = 0; i < STAGE_SLOTS; i++)
@@ -747,9 +746,9 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->ring_slots = 0;
     b->ring_seq = 0;
     b->d_dbg = nullptr;
-    b->h_snap2[0] = b->h_snap2[1] = nullptr;
-    b->snap_event2[0] = b->snap_event2[1] = nullptr;
-    b->snap_parity2[0] = b->snap_parity2[1] = 0;
+    b->h_pack[0] = b->h_pack[1] = nullptr;
+    b->d_pack[0] = b->d_pack[1] = nullptr;
+    b->snap_set2[0] = b->snap_set2[1] = 0;
     b->snap_head = b->snap_count = 0;
     b->h_stage = nullptr;
     for (unsigned i = 0; i < STAGE_SLOTS; i++) {
@@ -1426,6 +1425,33 @@ static int finish_window(const cmhip_batch_t *b, const VuState &v, unsigned pari
     return COOLMIC_ERROR_NONE;
 }
 
+// the same from a packed snapshot ([word][stream]: samples, C sums, C keys)
+static int finish_packed(const cmhip_batch_t *b, const unsigned long long *pack, unsigned s,
+                         coolmic_vumeter_result_t *out)
+{
+    const unsigned C = b->d.channels;
+    const size_t S = b->d.streams;
+    const unsigned long long frames = pack[s] / C;
+    if (frames == 0)
+        return COOLMIC_ERROR_INVAL;                      // ref: src/vumeter.c:198-199
+    memset(out, 0, sizeof(*out));
+    out->rate = b->d.rate;
+    out->channels = C;
+    out->frames = (size_t)frames;
+    unsigned long long all = 0, best = 0;
+    for (unsigned c = 0; c < C; c++) {
+        const unsigned long long power = pack[(size_t)(1u + c) * S + s], key = pack[(size_t)(1u + C + c) * S + s];
+        all += power;
+        out->channel_power[c] = power_db(power, frames);
+        out->channel_peak[c] = key_peak(key);
+        if (key > best)
+            best = key;
+    }
+    out->global_power = power_db(all, frames * C);
+    out->global_peak = key_peak(best);
+    return COOLMIC_ERROR_NONE;
+}
+
 extern "C" int cmhip_batch_vu_result(cmhip_batch_t *b, unsigned int stream,
                                      coolmic_vumeter_result_t *out)
 {
@@ -1457,11 +1483,13 @@ extern "C" int cmhip_batch_vu_snapshot(cmhip_batch_t *b)
         return fail(COOLMIC_ERROR_BUSY, "vu_snapshot: two snapshots are waiting to be collected");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
-    const size_t bytes = b->d.streams * sizeof(VuState);
     // The closed windows travel to the host on the copy stream and are cleared there, while
     // the main stream goes straight on with the next block into the next set.  Three sets
     // rotate so that the set a launch switches to was cleared a whole launch earlier: with
     // two, every launch waited for the copy + clear that ran beside its predecessor.
+    // One kernel does both (k_vu_pack): it writes what the host needs of every window -- 1 + 2C words,
+    // 40 bytes for stereo instead of the 264 of a VuState -- straight into pinned host memory and
+    // clears the set; its own dispatch stamps the set's event.
     const unsigned i = b->cur;
     const unsigned slot = (b->snap_head + b->snap_count) & 1u;
     if (b->last_done) {
@@ -1471,10 +1499,9 @@ extern "C" int cmhip_batch_vu_snapshot(cmhip_batch_t *b)
         HIP_TRY(hipEventRecord(b->ev_main, b->stream));
         HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_main, 0));
     }
-    HIP_TRY(hipMemcpyAsync(b->h_snap2[slot], b->d_vu2[i], bytes, hipMemcpyDeviceToHost, b->copy_stream));
-    HIP_TRY(hipEventRecord(b->snap_event2[slot], b->copy_stream));
-    HIP_TRY(hipMemsetAsync(b->d_vu2[i], 0, bytes, b->copy_stream));
-    HIP_TRY(hipEventRecord(b->ev_reset[i], b->copy_stream));
+    HIP_TRY(launch_vu_pack(b->d_vu2[i], b->d.streams, b->d.channels, b->parity, b->d_pack[slot], b->copy_stream,
+                           b->ev_reset[i]));
+    b->snap_set2[slot] = i;
     b->reset_pending[i] = true;
     b->cur = (i + 1u) % 3u;
     b->d_vu = b->d_vu2[b->cur];
@@ -1485,7 +1512,6 @@ extern "C" int cmhip_batch_vu_snapshot(cmhip_batch_t *b)
             HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_reset[b->cur], 0));
         b->reset_pending[b->cur] = false;
     }
-    b->snap_parity2[slot] = b->parity;
     b->snap_count++;
     return COOLMIC_ERROR_NONE;
 }
@@ -1499,7 +1525,7 @@ extern "C" int cmhip_batch_vu_collect(cmhip_batch_t *b, coolmic_vumeter_result_t
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     const unsigned slot = b->snap_head;
-    HIP_TRY(hipEventSynchronize(b->snap_event2[slot]));
+    HIP_TRY(hipEventSynchronize(b->ev_reset[b->snap_set2[slot]]));
     b->snap_head = (slot + 1u) & 1u;
     b->snap_count--;
     struct Job {
@@ -1511,15 +1537,19 @@ extern "C" int cmhip_batch_vu_collect(cmhip_batch_t *b, coolmic_vumeter_result_t
     auto body = [](void *p, unsigned lo, unsigned hi) {
         Job *j = (Job *)p;
         for (unsigned s = lo; s < hi; s++) {
-            const int r = finish_window(j->b, j->b->h_snap2[j->slot][s], j->b->snap_parity2[j->slot], &j->out[s]);
+            const int r = finish_packed(j->b, j->b->h_pack[j->slot], s, &j->out[s]);
             if (j->rc)
                 j->rc[s] = r;
         }
     };
     if (b->d.streams >= 512) {
         if (!b->pool) {
+            // (helpers beside the calling thread; $CMHIP_POOL_THREADS for hosts with a CPU quota below their
+            // core count)
             unsigned n = std::thread::hardware_concurrency() / 2;
-            n = n < 1 ? 1 : (n > 8 ? 8 : n);
+            n = n < 1 ? 1 : (n > 12 ? 12 : n);
+            if (const char *e = getenv("CMHIP_POOL_THREADS"))
+                n = atoi(e) > 0 ? (unsigned)atoi(e) : n;
             b->pool = new WorkPool(n);
         }
         b->pool->run(body, &job, b->d.streams);

@@ -152,6 +152,9 @@ hipError_t launch_node_partial(const VuState *vu, uint32_t streams, uint32_t cha
                                uint32_t parity, uint64_t first_global, uint64_t global_step,
                                long long *dst_sum, long long *dst_key, bool clear, hipStream_t st,
                                hipEvent_t ev_stop = nullptr);
+// (a set of windows -> [1 + 2C][streams] words in pinned, device-mapped host memory; clears the set)
+hipError_t launch_vu_pack(VuState *vu, uint32_t streams, uint32_t channels, uint32_t parity,
+                          unsigned long long *dst_host_mapped, hipStream_t st, hipEvent_t ev_stop);
 hipError_t launch_ceiling(int mode, const void *src, void *dst, size_t bytes,
                           unsigned long long *sink, hipStream_t st);
 

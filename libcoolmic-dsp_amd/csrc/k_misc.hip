@@ -187,6 +187,49 @@ hipError_t launch_node_partial(const VuState *vu, u32 streams, u32 channels, u32
 }
 
 // ---------------------------------------------------------------------------
+// Snapshot of a set of VU windows: what the host needs of a window -- the samples accounted, C sums of
+// squares, C packed peak keys; 1 + 2C words instead of the 33 of a VuState -- written by the kernel itself
+// into pinned, device-mapped host memory, word-major ([word][stream]: a wave stores 512 contiguous bytes per
+// instruction, whole lines over PCIe), and the device copy cleared for the set's next turn.  One launch on
+// the copy stream replaces a 264 B-per-stream copy, a clear of the same size and two event records.
+template <u32 NC>
+__global__ __launch_bounds__(64) void k_vu_pack(VuState *vu, u32 streams, u32 channels, u32 parity, u64 *dst)
+{
+    const u32 s = blockIdx.x * 64u + threadIdx.x;
+    if (s >= streams)
+        return;
+    VuState *v = vu + s;
+    dst[s] = v->samples[parity];
+#pragma unroll
+    for (u32 c = 0; c < NC; c++) {
+        if (c < channels) {
+            dst[(u64)(1u + c) * streams + s] = v->power[c];
+            dst[(u64)(1u + channels + c) * streams + s] = v->key[c];
+            v->power[c] = 0;
+            v->key[c] = 0;
+        }
+    }
+    v->samples[0] = 0;
+    v->samples[1] = 0;
+}
+
+hipError_t launch_vu_pack(VuState *vu, u32 streams, u32 channels, u32 parity, unsigned long long *dst_host_mapped,
+                          hipStream_t st, hipEvent_t ev_stop)
+{
+    const u32 grid = (streams + 63u) / 64u;
+    if (channels == 1)
+        hipExtLaunchKernelGGL(k_vu_pack<1>, dim3(grid), dim3(64), 0, st, nullptr, ev_stop, 0, vu, streams, channels, parity,
+                              dst_host_mapped);
+    else if (channels == 2)
+        hipExtLaunchKernelGGL(k_vu_pack<2>, dim3(grid), dim3(64), 0, st, nullptr, ev_stop, 0, vu, streams, channels, parity,
+                              dst_host_mapped);
+    else
+        hipExtLaunchKernelGGL(k_vu_pack<MAX_CH>, dim3(grid), dim3(64), 0, st, nullptr, ev_stop, 0, vu, streams, channels,
+                              parity, dst_host_mapped);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // Plain HBM ceilings over the same buffers: read-only sum, and copy.
 // Same access shape as k_run_fast -- one short-lived wave per 4 KiB tile, four
 // non-temporal 16-byte accesses per lane -- with no arithmetic, so the numbers are what
