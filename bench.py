@@ -600,16 +600,27 @@ def main():
                          "achieved_GBs": round(S * Cn * frames * bps / (ms / n * 1e-3) / 1e9, 1)}
                 for every, key in ((1, "step_ms_window_per_block"), (20, "step_ms_window_per_20_blocks")):
                     def loop(nsteps):
-                        pending = False
+                        # the dB finish of window k-1 runs on the helper threads beside launch k+1
+                        # (cmhip_batch_vu_collect_begin / _end); at most two snapshots are pending
+                        collecting, waiting = False, 0
                         for i in range(nsteps):
                             b.run(frames)
-                            if i % every == every - 1:
-                                b.vu_snapshot()
-                                if pending:
-                                    b.vu_collect(results, rcs)
-                                pending = True
-                        if pending:
+                            if i % every != every - 1:
+                                continue
+                            if collecting:
+                                b.vu_collect_end()
+                                collecting = False
+                            b.vu_snapshot()
+                            waiting += 1
+                            if waiting == 2:
+                                b.vu_collect_begin(results, rcs)
+                                collecting = True
+                                waiting -= 1
+                        if collecting:
+                            b.vu_collect_end()
+                        while waiting:
                             b.vu_collect(results, rcs)
+                            waiting -= 1
                         b.sync()
                     b.vu_reset(-1)
                     b.sync()

@@ -176,6 +176,12 @@ int cmhip_batch_vu_results(cmhip_batch_t *b, coolmic_vumeter_result_t *out, int 
  * collect waits for that copy and finishes the dB values on the host */
 int cmhip_batch_vu_snapshot(cmhip_batch_t *b);
 int cmhip_batch_vu_collect(cmhip_batch_t *b, coolmic_vumeter_result_t *out, int *rc);
+/* collect in two halves, for hosts that close a window every block of a few thousand frames: begin waits for
+ * the oldest snapshot and hands its windows to the helper threads, end returns when out[] and rc[] (which
+ * must stay valid until then) are complete; between the two the caller queues its next run.  One at a time;
+ * the snapshot keeps its place among the two that may be pending until end. */
+int cmhip_batch_vu_collect_begin(cmhip_batch_t *b, coolmic_vumeter_result_t *out, int *rc);
+int cmhip_batch_vu_collect_end(cmhip_batch_t *b);
 int cmhip_batch_vu_reset(cmhip_batch_t *b, long stream);
 /* raw accumulators of a stream (synchronises): power[16], peak[16], frames */
 int cmhip_batch_vu_raw(cmhip_batch_t *b, unsigned int stream, int64_t *power, int16_t *peak,

@@ -126,6 +126,8 @@ SIGNATURES = {
     "cmhip_batch_vu_results": (C.c_int, [_vp, _vp, _vp]),
     "cmhip_batch_vu_snapshot": (C.c_int, [_vp]),
     "cmhip_batch_vu_collect": (C.c_int, [_vp, _vp, _vp]),
+    "cmhip_batch_vu_collect_begin": (C.c_int, [_vp, _vp, _vp]),
+    "cmhip_batch_vu_collect_end": (C.c_int, [_vp]),
     "cmhip_batch_vu_reset": (C.c_int, [_vp, C.c_long]),
     "cmhip_batch_vu_raw": (C.c_int, [_vp, C.c_uint, _vp, _vp, _P(C.c_uint64)]),
     "cmhip_batch_vu_node_partial": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64]),
@@ -397,6 +399,14 @@ class Batch:
         rc = rc if rc is not None else (C.c_int * self.streams)()
         _check("vu_collect", lib.cmhip_batch_vu_collect(self.h, out, rc))
         return out, rc
+
+    def vu_collect_begin(self, out, rc):
+        """first half of vu_collect: the helper threads finish the oldest snapshot into out / rc (ctypes arrays
+        that must stay alive) while the caller goes on; vu_collect_end() returns when they are complete"""
+        _check("vu_collect_begin", lib.cmhip_batch_vu_collect_begin(self.h, out, rc))
+
+    def vu_collect_end(self):
+        _check("vu_collect_end", lib.cmhip_batch_vu_collect_end(self.h))
 
     def vu_reset(self, stream=-1):
         _check("vu_reset", lib.cmhip_batch_vu_reset(self.h, stream))

@@ -193,6 +193,10 @@ struct cmhip_batch {
     // device-mapped host memory that k_vu_pack writes itself (h_pack / d_pack: host / device view)
     unsigned long long *h_pack[2], *d_pack[2];
     unsigned int snap_set2[2];             // which of the three window sets the snapshot closed (its event: ev_reset)
+    bool collecting;                       // between cmhip_batch_vu_collect_begin and _end
+    coolmic_vumeter_result_t *job_out;
+    int *job_rc;
+    unsigned int job_slot;
     unsigned int snap_head, snap_count;    // ring of pending snapshots (oldest = head)
     unsigned char *h_stage;                // pinned upload ring, STAGE_SLOTS x STAGE_BYTES
     hipEvent_t stage_ev[4];
@@ -301,6 +305,8 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     if (!b)
         return;
     (void)hipSetDevice(b->d.device);
+    if (b->collecting)
+        (void)cmhip_batch_vu_collect_end(b);
     if (b->stream)
         (void)hipStreamSynchronize(b->stream);
     for (auto &e : b->ev_used) {
@@ -749,6 +755,10 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->h_pack[0] = b->h_pack[1] = nullptr;
     b->d_pack[0] = b->d_pack[1] = nullptr;
     b->snap_set2[0] = b->snap_set2[1] = 0;
+    b->collecting = false;
+    b->job_out = nullptr;
+    b->job_rc = nullptr;
+    b->job_slot = 0;
     b->snap_head = b->snap_count = 0;
     b->h_stage = nullptr;
     for (unsigned i = 0; i < STAGE_SLOTS; i++) {
@@ -1516,32 +1526,37 @@ extern "C" int cmhip_batch_vu_snapshot(cmhip_batch_t *b)
     return COOLMIC_ERROR_NONE;
 }
 
-extern "C" int cmhip_batch_vu_collect(cmhip_batch_t *b, coolmic_vumeter_result_t *out, int *rc)
+static void collect_body(void *p, unsigned lo, unsigned hi)
+{
+    cmhip_batch_t *b = (cmhip_batch_t *)p;
+    for (unsigned s = lo; s < hi; s++) {
+        const int r = finish_packed(b, b->h_pack[b->job_slot], s, &b->job_out[s]);
+        if (b->job_rc)
+            b->job_rc[s] = r;
+    }
+}
+
+// The dB finish of the oldest snapshot, in two halves: begin() waits for the snapshot's data and hands the
+// windows to the helper pool, end() takes what is left itself and returns when out[] / rc[] are complete.
+// Between the two the caller queues the next block -- with a window per block of a few thousand frames the
+// host's finish (thousands of log10 per step) is as long as the kernel, and only beside the next launch does
+// it stop counting.  cmhip_batch_vu_collect() is the two in one.
+extern "C" int cmhip_batch_vu_collect_begin(cmhip_batch_t *b, coolmic_vumeter_result_t *out, int *rc)
 {
     if (!b || !out)
         return fail(COOLMIC_ERROR_FAULT, "vu_collect: NULL argument");
+    if (b->collecting)
+        return fail(COOLMIC_ERROR_BUSY, "vu_collect_begin: the collect before has not been ended");
     if (b->snap_count == 0)
         return fail(COOLMIC_ERROR_INVAL, "vu_collect: no snapshot pending");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     const unsigned slot = b->snap_head;
     HIP_TRY(hipEventSynchronize(b->ev_reset[b->snap_set2[slot]]));
-    b->snap_head = (slot + 1u) & 1u;
-    b->snap_count--;
-    struct Job {
-        cmhip_batch_t *b;
-        coolmic_vumeter_result_t *out;
-        int *rc;
-        unsigned slot;
-    } job = {b, out, rc, slot};
-    auto body = [](void *p, unsigned lo, unsigned hi) {
-        Job *j = (Job *)p;
-        for (unsigned s = lo; s < hi; s++) {
-            const int r = finish_packed(j->b, j->b->h_pack[j->slot], s, &j->out[s]);
-            if (j->rc)
-                j->rc[s] = r;
-        }
-    };
+    b->job_out = out;
+    b->job_rc = rc;
+    b->job_slot = slot;
+    b->collecting = true;                    // (the snapshot keeps its place in the ring until end())
     if (b->d.streams >= 512) {
         if (!b->pool) {
             // (helpers beside the calling thread; $CMHIP_POOL_THREADS for hosts with a CPU quota below their
@@ -1552,11 +1567,31 @@ extern "C" int cmhip_batch_vu_collect(cmhip_batch_t *b, coolmic_vumeter_result_t
                 n = atoi(e) > 0 ? (unsigned)atoi(e) : n;
             b->pool = new WorkPool(n);
         }
-        b->pool->run(body, &job, b->d.streams);
-    } else {
-        body(&job, 0, b->d.streams);
+        b->pool->start(collect_body, b, b->d.streams);
     }
     return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_vu_collect_end(cmhip_batch_t *b)
+{
+    if (!b)
+        return fail(COOLMIC_ERROR_FAULT, "vu_collect_end: batch is NULL");
+    if (!b->collecting)
+        return fail(COOLMIC_ERROR_INVAL, "vu_collect_end: no collect under way");
+    if (b->d.streams >= 512)
+        b->pool->finish();
+    else
+        collect_body(b, 0, b->d.streams);
+    b->collecting = false;
+    b->snap_head = (b->snap_head + 1u) & 1u;
+    b->snap_count--;
+    return COOLMIC_ERROR_NONE;
+}
+
+extern "C" int cmhip_batch_vu_collect(cmhip_batch_t *b, coolmic_vumeter_result_t *out, int *rc)
+{
+    const int r = cmhip_batch_vu_collect_begin(b, out, rc);
+    return r != COOLMIC_ERROR_NONE ? r : cmhip_batch_vu_collect_end(b);
 }
 
 extern "C" int cmhip_batch_vu_results(cmhip_batch_t *b, coolmic_vumeter_result_t *out, int *rc)

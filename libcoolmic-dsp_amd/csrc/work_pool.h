@@ -119,7 +119,10 @@ struct WorkPool {
             }
         }
     }
-    void run(void (*f)(void *, unsigned, unsigned), void *a, unsigned tot, unsigned per_chunk = 64)
+    // start() hands a job to the helpers and returns; finish() takes whatever chunks are left itself and
+    // waits for the helpers' last ones.  Between the two the caller does something else (the next launch);
+    // run() is the two in one.  One job at a time: no start() before the finish() of the job before.
+    void start(void (*f)(void *, unsigned, unsigned), void *a, unsigned tot, unsigned per_chunk = 64)
     {
         bool wake;
         {
@@ -134,7 +137,15 @@ struct WorkPool {
         }
         if (wake)
             cv_work.notify_all();
-        drain(f, a, tot);                             // the caller works as well
+    }
+    void run(void (*f)(void *, unsigned, unsigned), void *a, unsigned tot, unsigned per_chunk = 64)
+    {
+        start(f, a, tot, per_chunk);
+        finish();
+    }
+    void finish()
+    {
+        drain(fn, arg, total);                        // the caller works as well
         // chunks taken by helpers may still be running: they are short, so look before sleeping.
         // The last look is under the lock: a helper may be between finding chunks left and counting
         // itself in (it holds the lock there), and must be waited for like the others.

@@ -1,5 +1,5 @@
 // pool_test.cpp -- WorkPool (libcoolmic-dsp_amd/csrc/work_pool.h) without a GPU: many jobs of
-// different sizes and chunkings from one caller, with pauses on both sides of the helpers' spin
+// different sizes and chunkings from one caller (run(), and start() ... finish() with the caller away in between), with pauses on both sides of the helpers' spin
 // window, every item counted exactly once.  Built by tests/test_work_pool.py (also under
 // ThreadSanitizer where the toolchain has it).
 #include <stdio.h>
@@ -28,11 +28,19 @@ int main(int argc, char **argv)
             for (unsigned i = 0; i < n; i++)
                 hits[i].store(0, std::memory_order_relaxed);
             Job job = {&hits, (unsigned)j};
-            pool.run([](void *p, unsigned lo, unsigned hi) {
+            auto body = [](void *p, unsigned lo, unsigned hi) {
                 Job *q = (Job *)p;
                 for (unsigned i = lo; i < hi; i++)
                     (*q->hits)[i].fetch_add(1 + (q->salt & 1u), std::memory_order_relaxed);
-            }, &job, n, chunk);
+            };
+            if (j % 3 == 2) {                         // the two-phase form: the caller is away in between
+                pool.start(body, &job, n, chunk);
+                if (j % 12 == 2)
+                    std::this_thread::sleep_for(std::chrono::microseconds(30));
+                pool.finish();
+            } else {
+                pool.run(body, &job, n, chunk);
+            }
             for (unsigned i = 0; i < n; i++) {
                 const unsigned h = hits[i].load(std::memory_order_relaxed);
                 if (h != 1 + ((unsigned)j & 1u)) {

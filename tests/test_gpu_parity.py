@@ -511,6 +511,49 @@ def test_results_for_all_streams_and_snapshot_overlap(gpu, oracle):
     b.close()
 
 
+@pytest.mark.parametrize("S,C", [(700, 2), (1500, 1), (600, 5)])
+def test_window_per_block_with_the_collect_in_two_halves(gpu, oracle, S, C):
+    """The small-block loop of bench.py: a VU window per block, the snapshot packed by one kernel into host
+    memory (1 + 2C words per window), the dB finish begun on the helper threads and ended a launch later
+    (cmhip_batch_vu_collect_begin / _end; S >= 512: the pool works).  Every block's windows of sampled
+    streams against the oracle; the ring of two pending snapshots refuses a third; begin twice is refused."""
+    import ctypes as Ct
+    cm = gpu
+    T, blocks = 480, 9
+    b = cm.Batch(S, C, T, flags=cm.VU | cm.OUT_PCM)
+    gains = [750, 1250, 900, 1000, 300][:C]
+    assert b.set_gain(-1, C, 1000, gains) == 0
+    outs = [((cm.VuResult * S)(), (Ct.c_int * S)()) for _ in range(blocks)]
+    collecting = None
+    begun = []
+    for k in range(blocks):
+        b.generate(cm.GEN_NOISE, 4000 + k, T)
+        b.run(T)
+        if collecting is not None:
+            b.vu_collect_end()
+            collecting = None
+        b.vu_snapshot()
+        if k >= 1:
+            assert cm.lib.cmhip_batch_vu_snapshot(b.h) == cm.ERROR_BUSY          # two are pending
+            b.vu_collect_begin(*outs[k - 1])
+            assert cm.lib.cmhip_batch_vu_collect_begin(b.h, outs[k][0], outs[k][1]) == cm.ERROR_BUSY
+            collecting = k - 1
+            begun.append(k - 1)
+    b.vu_collect_end()
+    b.vu_collect(*outs[blocks - 1])
+    assert cm.lib.cmhip_batch_vu_collect_end(b.h) == cm.ERROR_INVAL
+    for k in range(blocks):
+        res, rcs = outs[k]
+        for s in (0, 1, 63, 64, S // 2, S - 1):
+            want = _oracle_block(oracle, oracle.lcg(4000 + k + s, T * C), C, (C, 1000, gains), None)
+            _, ro = _oracle_vu(oracle, [want], C)
+            assert rcs[s] == 0 and res[s].as_dict() == of.vu_result_dict(ro), (k, s)
+    # a window nobody filled: INVAL for every stream, as coolmic_vumeter_result (ref: src/vumeter.c:198-199)
+    res, rcs = b.vu_results()
+    assert all(r == cm.ERROR_INVAL for r in rcs)
+    b.close()
+
+
 def test_node_partial_matches_host_merge(gpu, oracle):
     """config 5's per-GPU record; two 'ranks' emulated as two batches on this GPU and
     combined on the host the way the all-reduce combines them (SUM / MAX)"""
