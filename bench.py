@@ -600,24 +600,25 @@ def main():
                          "achieved_GBs": round(S * Cn * frames * bps / (ms / n * 1e-3) / 1e9, 1)}
                 for every, key in ((1, "step_ms_window_per_block"), (20, "step_ms_window_per_20_blocks")):
                     def loop(nsteps):
-                        # the dB finish of window k-1 runs on the helper threads beside launch k+1
-                        # (cmhip_batch_vu_collect_begin / _end); at most two snapshots are pending
+                        # the dB finish of window k-1 runs on the helper threads beside launch and snapshot of
+                        # block k+1 (cmhip_batch_vu_collect_begin / _end); up to three snapshots are pending
                         collecting, waiting = False, 0
                         for i in range(nsteps):
                             b.run(frames)
                             if i % every != every - 1:
                                 continue
+                            b.vu_snapshot()
+                            waiting += 1
                             if collecting:
                                 b.vu_collect_end()
                                 collecting = False
-                            b.vu_snapshot()
-                            waiting += 1
-                            if waiting == 2:
+                                waiting -= 1
+                            if waiting >= 2:
                                 b.vu_collect_begin(results, rcs)
                                 collecting = True
-                                waiting -= 1
                         if collecting:
                             b.vu_collect_end()
+                            waiting -= 1
                         while waiting:
                             b.vu_collect(results, rcs)
                             waiting -= 1

@@ -179,7 +179,8 @@ int cmhip_batch_vu_collect(cmhip_batch_t *b, coolmic_vumeter_result_t *out, int 
 /* collect in two halves, for hosts that close a window every block of a few thousand frames: begin waits for
  * the oldest snapshot and hands its windows to the helper threads, end returns when out[] and rc[] (which
  * must stay valid until then) are complete; between the two the caller queues its next run.  One at a time;
- * the snapshot keeps its place among the two that may be pending until end. */
+ * the snapshot keeps its place among the three that may be pending (cmhip_batch_vu_snapshot returns
+ * COOLMIC_ERROR_BUSY for a fourth) until end. */
 int cmhip_batch_vu_collect_begin(cmhip_batch_t *b, coolmic_vumeter_result_t *out, int *rc);
 int cmhip_batch_vu_collect_end(cmhip_batch_t *b);
 int cmhip_batch_vu_reset(cmhip_batch_t *b, long stream);

@@ -189,10 +189,11 @@ struct cmhip_batch {
     unsigned int nsec;
     bool eq_dirty;
 
-    // two snapshots may be in flight: each a packed copy of a window set, [1 + 2C][S] words in pinned,
-    // device-mapped host memory that k_vu_pack writes itself (h_pack / d_pack: host / device view)
-    unsigned long long *h_pack[2], *d_pack[2];
-    unsigned int snap_set2[2];             // which of the three window sets the snapshot closed (its event: ev_reset)
+    // three snapshots may be pending (one being finished by the helper threads, one waiting, one on its way):
+    // each a packed copy of a window set, [1 + 2C][S] words in pinned, device-mapped host memory that
+    // k_vu_pack writes itself (h_pack / d_pack: host / device view)
+    unsigned long long *h_pack[3], *d_pack[3];
+    unsigned int snap_set2[3];             // which of the three window sets the snapshot closed (its event: ev_reset)
     bool collecting;                       // between cmhip_batch_vu_collect_begin and _end
     coolmic_vumeter_result_t *job_out;
     int *job_rc;
@@ -358,7 +359,7 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     if (b->h_ring)
         (void)hipHostFree(b->h_ring);
     (void)hipFree(b->d_dbg);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 3; i++)
         if (b->h_pack[i])
             (void)hipHostFree(b->h_pack[i]);
     if (b->h_stage)
@@ -666,7 +667,7 @@ static int batch_init(cmhip_batch_t *b)
         HIP_TRY(hipMemsetAsync(b->d_eqstate, 0, S * d.channels * sizeof(EqState), b->stream));
         b->h_eq.assign(S, EqParam{});
     }
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         HIP_TRY(hipHostMalloc((void **)&b->h_pack[i], S * (1u + 2u * d.channels) * sizeof(unsigned long long),
                               hipHostMallocMapped));
         HIP_TRY(hipHostGetDevicePointer((void **)&b->d_pack[i], b->h_pack[i], 0));
@@ -752,9 +753,9 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->ring_slots = 0;
     b->ring_seq = 0;
     b->d_dbg = nullptr;
-    b->h_pack[0] = b->h_pack[1] = nullptr;
-    b->d_pack[0] = b->d_pack[1] = nullptr;
-    b->snap_set2[0] = b->snap_set2[1] = 0;
+    b->h_pack[0] = b->h_pack[1] = b->h_pack[2] = nullptr;
+    b->d_pack[0] = b->d_pack[1] = b->d_pack[2] = nullptr;
+    b->snap_set2[0] = b->snap_set2[1] = b->snap_set2[2] = 0;
     b->collecting = false;
     b->job_out = nullptr;
     b->job_rc = nullptr;
@@ -1489,8 +1490,8 @@ extern "C" int cmhip_batch_vu_snapshot(cmhip_batch_t *b)
         return fail(COOLMIC_ERROR_FAULT, "vu_snapshot: batch is NULL");
     if (!(b->d.flags & CMHIP_VU))
         return fail(COOLMIC_ERROR_INVAL, "vu_snapshot: batch without VU");
-    if (b->snap_count == 2)
-        return fail(COOLMIC_ERROR_BUSY, "vu_snapshot: two snapshots are waiting to be collected");
+    if (b->snap_count == 3)
+        return fail(COOLMIC_ERROR_BUSY, "vu_snapshot: three snapshots are waiting to be collected");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     // The closed windows travel to the host on the copy stream and are cleared there, while
@@ -1501,7 +1502,7 @@ extern "C" int cmhip_batch_vu_snapshot(cmhip_batch_t *b)
     // 40 bytes for stereo instead of the 264 of a VuState -- straight into pinned host memory and
     // clears the set; its own dispatch stamps the set's event.
     const unsigned i = b->cur;
-    const unsigned slot = (b->snap_head + b->snap_count) & 1u;
+    const unsigned slot = (b->snap_head + b->snap_count) % 3u;
     if (b->last_done) {
         HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->last_done, 0));
         b->last_done = nullptr;
@@ -1583,7 +1584,7 @@ extern "C" int cmhip_batch_vu_collect_end(cmhip_batch_t *b)
     else
         collect_body(b, 0, b->d.streams);
     b->collecting = false;
-    b->snap_head = (b->snap_head + 1u) & 1u;
+    b->snap_head = (b->snap_head + 1u) % 3u;
     b->snap_count--;
     return COOLMIC_ERROR_NONE;
 }

@@ -525,20 +525,19 @@ def test_window_per_block_with_the_collect_in_two_halves(gpu, oracle, S, C):
     assert b.set_gain(-1, C, 1000, gains) == 0
     outs = [((cm.VuResult * S)(), (Ct.c_int * S)()) for _ in range(blocks)]
     collecting = None
-    begun = []
     for k in range(blocks):
         b.generate(cm.GEN_NOISE, 4000 + k, T)
         b.run(T)
+        b.vu_snapshot()                      # pending now: k-1 being finished, (k) new -- or k-2, k-1, k
+        if k >= 2:
+            assert cm.lib.cmhip_batch_vu_snapshot(b.h) == cm.ERROR_BUSY          # three are pending
         if collecting is not None:
             b.vu_collect_end()
             collecting = None
-        b.vu_snapshot()
         if k >= 1:
-            assert cm.lib.cmhip_batch_vu_snapshot(b.h) == cm.ERROR_BUSY          # two are pending
             b.vu_collect_begin(*outs[k - 1])
             assert cm.lib.cmhip_batch_vu_collect_begin(b.h, outs[k][0], outs[k][1]) == cm.ERROR_BUSY
             collecting = k - 1
-            begun.append(k - 1)
     b.vu_collect_end()
     b.vu_collect(*outs[blocks - 1])
     assert cm.lib.cmhip_batch_vu_collect_end(b.h) == cm.ERROR_INVAL
@@ -956,8 +955,10 @@ def test_batch_api_error_paths(gpu):
     r = (cm.VuResult * 2)()
     assert cm.lib.cmhip_batch_vu_collect(b.h, r, None) == cm.ERROR_INVAL    # no snapshot pending
     b.vu_snapshot()
-    b.vu_snapshot()                                               # two may be in flight
+    b.vu_snapshot()
+    b.vu_snapshot()                                               # three may be pending
     assert cm.lib.cmhip_batch_vu_snapshot(b.h) == cm.ERROR_BUSY
+    b.vu_collect()
     b.vu_collect()
     b.vu_collect()
     assert cm.lib.cmhip_batch_run(None, 1, None) == cm.ERROR_FAULT
