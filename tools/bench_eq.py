@@ -4,7 +4,6 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: F401  (torch's HIP runtime first)
 import __graft_entry__ as ge
 
 cm = ge.load_package()

@@ -11,7 +11,8 @@ OUT=$ROOT/gpurun_out/hbm_pmc_$WL
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d "$OUT/$c" -- python3 "$ROOT/bench.py" --workload "$WL" \
+    # (the batch's arrays where hipMalloc first puts them: no probe launches of a placement search among the dispatches)
+    COOLMIC_BENCH_PLACE=0 rocprofv3 --pmc $c --output-format csv -d "$OUT/$c" -- python3 "$ROOT/bench.py" --workload "$WL" \
         --steps 5 --warmup 1 --no-cpu --no-extras > "$OUT/$c.json" 2> "$OUT/$c.err"
 done
 python3 - "$OUT" "$WL" "$ROOT/gpurun_out/pmc_$WL.json" <<'PY'
@@ -31,7 +32,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 rd = raw["FETCH_SIZE"]["mean_KiB"] * 1024 * 2
 wr = raw["WRITE_SIZE"]["mean_KiB"] * 1024
 alg = line["roofline"]["algorithmic_bytes_per_launch"]
-res = {"round": "round 2", "workload": wl, "streams": line["config"]["streams_per_gpu"], "channels": line["config"]["channels"],
+res = {"round": "round 3", "workload": wl, "streams": line["config"]["streams_per_gpu"], "channels": line["config"]["channels"],
        "frames": line["config"]["frames_per_launch"], "kernel": name,
        "command": "tools/hbm_pmc.sh %s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, one counter per pass, bench.py --steps 5 --warmup 1 --no-cpu --no-extras)" % wl,
        "raw": raw,

@@ -1,6 +1,8 @@
 #!/bin/bash
-# Round-end checks on the GPU box: GPU tests, smoke, the default bench line, rocprofv3 kernel stats of
-# configs 3 and 2 and of the six-channel workload x6, HBM counters of the three (tools/hbm_pmc.sh).  Everything lands under gpurun_out/.
+# Round-end checks on the GPU box (one gpurun call): GPU tests, smoke, the default bench line, rocprofv3 kernel
+# stats of configs 2 and 3 and of the six-channel workload x6, HBM counters of the three (tools/hbm_pmc.sh), the
+# N = 1 lines of the other workloads, the two-rank rehearsal, the tables DESIGN.md quotes.  Everything lands
+# under gpurun_out/; tools/collect_profiles.sh copies what is kept into profiles/.
 set -e
 R=$PWD
 mkdir -p gpurun_out
@@ -10,27 +12,34 @@ timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()"
 timeout -k 10 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 cat gpurun_out/bench_default.json
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/prof_c3 $R/gpurun_out/prof_c2
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3 -- python3 $R/bench.py --workload c3 --steps 100 --warmup 100 --no-cpu --no-extras > $R/gpurun_out/c3_rocprof.json 2> $R/gpurun_out/c3_rocprof.err
-cat $R/gpurun_out/c3_rocprof.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2 -- python3 $R/bench.py --steps 100 --warmup 100 --no-cpu --no-extras > $R/gpurun_out/c2_rocprof.json 2> $R/gpurun_out/c2_rocprof.err
-cat $R/gpurun_out/c2_rocprof.json
-rm -rf $R/gpurun_out/prof_x6
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_x6 -- python3 $R/bench.py --workload x6 --steps 100 --warmup 100 --no-cpu --no-extras > $R/gpurun_out/x6_rocprof.json 2> $R/gpurun_out/x6_rocprof.err
-cat $R/gpurun_out/x6_rocprof.json
+prof() {    # name, environment assignment, bench arguments...
+    local name=$1 envs=$2; shift 2
+    rm -rf $R/gpurun_out/prof_$name
+    env $envs timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$name -- \
+        python3 $R/bench.py "$@" --steps 100 --warmup 100 --no-cpu --no-extras > $R/gpurun_out/${name}_rocprof.json 2> $R/gpurun_out/${name}_rocprof.err
+    cat $R/gpurun_out/${name}_rocprof.json
+}
+# the batch's arrays where hipMalloc first puts them: every launch of the kernel in the trace is a step of the bench
+prof c2 COOLMIC_BENCH_PLACE=0
+# with the engine's placement search, as the default line runs: the trace also holds the search's probe launches
+# and the place-off leg's (setup.placement.probe_launches and 64 + warm-up in the line say how many)
+prof c2_search COOLMIC_BENCH_PLACE=1
+prof c3 COOLMIC_BENCH_PLACE=0 --workload c3
+prof x6 COOLMIC_BENCH_PLACE=0 --workload x6
 cd $R
-timeout -k 10 300 bash tools/hbm_pmc.sh c2 > gpurun_out/hbm_c2.log 2>&1 && tail -8 gpurun_out/hbm_c2.log
-timeout -k 10 300 bash tools/hbm_pmc.sh c3 > gpurun_out/hbm_c3.log 2>&1 && tail -8 gpurun_out/hbm_c3.log
-timeout -k 10 300 bash tools/hbm_pmc.sh x6 > gpurun_out/hbm_x6.log 2>&1 && tail -8 gpurun_out/hbm_x6.log
-# the N = 1 lines of the other workloads (config 5 with a one-rank RCCL communicator: all a 1-GPU box holds),
-# the 2-rank rehearsal of the self-launching bench on one GPU, and the tables DESIGN.md quotes
+for w in c2 c3 x6; do
+    timeout -k 10 300 bash tools/hbm_pmc.sh $w > gpurun_out/hbm_$w.log 2>&1 && tail -8 gpurun_out/hbm_$w.log
+done
 timeout -k 10 300 python bench.py --workload c4 --no-extras --no-cpu > gpurun_out/n1_c4.json 2> gpurun_out/n1_c4.err
 timeout -k 10 300 env COOLMIC_BENCH_FORCE_NODE=1 python bench.py --workload c5 --no-extras --no-cpu > gpurun_out/n1_c5.json 2> gpurun_out/n1_c5.err
 timeout -k 10 300 python bench.py --workload c3 --no-cpu > gpurun_out/n1_c3.json 2> gpurun_out/n1_c3.err
-timeout -k 10 300 env COOLMIC_BENCH_REHEARSAL=1 python bench.py --gpus 2 --workload c5 --steps 100 --warmup 20 --no-extras --no-cpu > gpurun_out/rehearsal_c5_2ranks.json 2> gpurun_out/rehearsal_c5_2ranks.err
+# the driver's multi-GPU command on the one GPU: two ranks share device 0 (not a scaling number); the line carries
+# the config-4 / config-5 legs (node_vu)
+timeout -k 10 400 env COOLMIC_BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 100 --warmup 20 --no-extras --no-cpu > gpurun_out/rehearsal_2ranks.json 2> gpurun_out/rehearsal_2ranks.err
+cat gpurun_out/rehearsal_2ranks.json
 timeout -k 10 300 python tools/bench_generic.py > gpurun_out/table_many_channels.txt 2>&1
 timeout -k 10 300 python tools/bench_eq.py > gpurun_out/table_eq.txt 2>&1
-timeout -k 10 300 python tools/bench_eq_sections.py > gpurun_out/table_eq_sections.txt 2>&1
-timeout -k 10 120 python tools/bench_chain.py > gpurun_out/table_chain.txt 2>&1
-timeout -k 10 900 bash tools/eq_pmc.sh > gpurun_out/eq_sq_counters.txt 2>&1
-tail -25 gpurun_out/eq_sq_counters.txt
+gcc -std=gnu11 -O2 -I include examples/product_chain.c -L libcoolmic-dsp_amd/lib -lcoolmic-dsp-hip -lpthread \
+    -Wl,-rpath,$R/libcoolmic-dsp_amd/lib -o /tmp/product_chain
+timeout -k 10 120 /tmp/product_chain 8000 > gpurun_out/table_chain.txt 2>&1
+cat gpurun_out/table_chain.txt
