@@ -13,7 +13,6 @@ BITS = {1: "store wave idle", 2: "no global loads (synthetic PCM)", 4: "recurren
 CHILD = r'''
 import sys, os
 sys.path.insert(0, %r)
-import torch
 import __graft_entry__ as ge
 cm = ge.load_package()
 S, T = 8192, 65536

@@ -5,7 +5,6 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: F401
 import __graft_entry__ as ge
 
 cm = ge.load_package()
