@@ -59,14 +59,6 @@ __device__ __forceinline__ int f32_to_i16(float y)
 // Sensitivity builds (`make variant NAME=pad_r DEFS=-DCMHIP_EQ_PAD_R=32`, tools/ab_two_libs.py): N extra
 // VALU instructions per step in the waves of one role.  What the launch time gains per padded
 // instruction says which role the step waits for.  Never defined in the product.
-// Experiment of round 3 (`make variant NAME=uneven DEFS=-DCMHIP_EQ_UNEVEN=1`; never defined in the product):
-// an UNEVEN deal of the rows among the four T-in waves.  The two that share a SIMD with an R wave are last at
-// the barrier in 95 % of the steps (profiles/r02_eq_stamps.txt); here they take 4 rows instead of 8, in a
-// shape that halves their instruction count (lane = row x 4-frame chunk, 16 lanes per row), and the two beside a
-// T-ff wave take 12 (their pass of 8 rows x 8-frame chunks plus such a pass of 4).  Mono rows only.
-#ifndef CMHIP_EQ_UNEVEN
-#define CMHIP_EQ_UNEVEN 0
-#endif
 #ifndef CMHIP_EQ_PAD_R
 #define CMHIP_EQ_PAD_R 0
 #endif
@@ -215,17 +207,13 @@ void k_eq_pipe(EqArgs a)
     }
 
     // T lanes: stream row l_r, frames l_t8 .. l_t8+7 of every block
-    constexpr bool UNEVEN = MONO && CMHIP_EQ_UNEVEN != 0 && NTF == 2 && NRW == 2;
-    // UNEVEN: T-in 0 and 3 (beside the T-ff waves) run the pass of 8 rows -- rows 0-7 and 20-27 -- and a
-    // quad pass; T-in 1 and 2 (beside the R waves) a quad pass only.  Quad rows: 8-11, 12-15, 16-19, 28-31.
-    const bool t_full = !UNEVEN || !is_tin || tw == 0u || tw == 3u;
-    const u32 l_r = (UNEVEN && is_tin ? (tw == 3u ? 20u : 0u) : 8u * tw) + lane / 8u;
+    const u32 l_r = 8u * tw + lane / 8u;
     const u32 l_c = lane % 8u;
     const u32 l_t8 = l_c * 8u;
     u32 l_ch;
     const u32 l_stream = row_stream(l_r, l_ch);
     const u32 l_s = min(l_stream, a.streams - 1);
-    const bool l_live = is_tin && t_full && l_stream < a.streams;
+    const bool l_live = is_tin && l_stream < a.streams;
     const u32 l_sidx = l_s * C + l_ch;
     u32 l_magic = 0, l_shift = 0, l_g2 = 0, l_n = 0, l_m = 0;
     // feed-forward registers: b0 b1 b2 and x[t-1], x[t-2] before the next block.  A T-in lane
@@ -260,31 +248,6 @@ void k_eq_pipe(EqArgs a)
             sx2[0][0] = st[1] * 32768.0f;
         }
     }
-    // UNEVEN: the quad pass of a T-in wave -- lane = row q_r x 4-frame chunk q_c (a row is one DPP row of 16 lanes)
-    const u32 q_r = (tw == 0u ? 8u : tw == 1u ? 12u : tw == 2u ? 16u : 28u) + lane / 16u;
-    const u32 q_c = lane % 16u, q_t4 = q_c * 4u;
-    u32 q_chn;
-    const u32 q_stream = row_stream(min(q_r, (u32)G - 1u), q_chn);
-    const u32 q_s = min(q_stream, a.streams - 1);
-    const bool q_live = UNEVEN && is_tin && q_stream < a.streams;
-    const u32 q_sidx = q_s * C + q_chn;
-    u32 q_magic = 0, q_shift = 0, q_g2 = 2u, q_n = 0;
-    float qc0 = 0.f, qc1 = 0.f, qc2 = 0.f, qx1 = 0.f, qx2 = 0.f;
-    if (UNEVEN && is_tin) {
-        q_magic = a.param[q_s].magic;
-        q_shift = a.param[q_s].shift;
-        q_g2 = a.param[q_s].gain2[q_chn];
-        q_n = nfr_lds[min(q_r, (u32)G - 1u)];
-        if (q_live) {
-            const float *c = a.eq[q_s].coef[0];
-            const float *st = a.state[q_sidx].s[0];
-            qc0 = c[0] * (1.0f / 32768.0f);
-            qc1 = c[1] * (1.0f / 32768.0f);
-            qc2 = c[2] * (1.0f / 32768.0f);
-            qx1 = st[0] * 32768.0f;
-            qx2 = st[1] * 32768.0f;
-        }
-    }
     u32 f_r[PASSES];                                      // T-ff: row of pass p
 #pragma unroll
     for (u32 p = 0; p < PASSES; p++) {
@@ -313,7 +276,7 @@ void k_eq_pipe(EqArgs a)
     }
 
     // gain disabled (scale 0, or every gain equal to the scale) is stored as 1/1: x -> x
-    const bool gain_off = __all((!t_full || (l_g2 == 2u && l_shift == 0u)) && (!UNEVEN || (q_g2 == 2u && q_shift == 0u)));
+    const bool gain_off = __all(l_g2 == 2u && l_shift == 0u);
 
     // The T waves keep two blocks of PCM in flight: a block's HBM latency is hidden behind
     // two pipeline steps.  The load is unconditional (address clamped into the stream's own
@@ -364,38 +327,9 @@ void k_eq_pipe(EqArgs a)
         keep2 = l_n >= 2u ? gain_one(l_n - 2u) : a.state[l_sidx].s[0][0];
     }
     Pcm wa = {{0, 0, 0, 0}, {0, 0, 0, 0}}, wb = wa;       // blocks of even / odd steps
-    if (is_tin && t_full) {
+    if (is_tin) {
         wa = fetch(0);
         wb = fetch(1);
-    }
-    // UNEVEN, the quad pass: 4 frames (8 bytes) per lane, two blocks in flight as above
-    typedef u32 u32x2q __attribute__((ext_vector_type(2)));
-    const int16_t *q_src = a.in + (u64)q_s * a.stride;
-    const u32 q_last = (u32)a.stride - 4u;
-    auto fetchq = [&](u32 b) -> u32x2q {
-        const u32 f0 = b * EP_TB + q_t4;
-        return __builtin_nontemporal_load(reinterpret_cast<const u32x2q *>(q_src + min(f0, q_last)));
-    };
-    float qkeep1 = 0.f, qkeep2 = 0.f;
-    u32 qkeep_n = 0;
-    u32x2q qa = {0, 0}, qb = {0, 0};
-    if constexpr (UNEVEN) {
-        if (is_tin) {
-            if (q_live && q_c == 0u && q_n >= 1u) {           // section 0's x1 / x2 for the next launch (as keep1 / keep2)
-                auto gain_q = [&](const u32 frame) -> float {
-                    const int xs = (int)q_src[frame];
-                    const u32 ax = (u32)(xs < 0 ? -xs : xs);
-                    const u32 qq = __umulhi(__umul24(ax, q_g2), q_magic) >> q_shift;
-                    const float m = fminf((float)qq, xs < 0 ? 32768.0f : 32767.0f);
-                    return (xs < 0 ? -m : m) * (1.0f / 32768.0f);
-                };
-                qkeep_n = 3u;
-                qkeep1 = gain_q(q_n - 1u);
-                qkeep2 = q_n >= 2u ? gain_q(q_n - 2u) : a.state[q_sidx].s[0][0];
-            }
-            qa = fetchq(0);
-            qb = fetchq(1);
-        }
     }
 
     // feed-forward half of section k on the 8 samples of this lane; the two samples before
@@ -595,53 +529,6 @@ void k_eq_pipe(EqArgs a)
 #endif
             }
         }
-    };
-    // UNEVEN: the quad pass -- the same chain as tin_step on 4 frames per lane: PCM -> gain -> float ->
-    // feed-forward of section 0 -> F_0 (one b128 per lane); x[t-1], x[t-2] from the lane to the left
-    // (row_shr:1), those of a block's first chunk from the row's last lane of the step before (row_shl:15)
-    auto tinq_step = [&](u32x2q &wcur, const u32 step) {
-        constexpr int DPP_SHL15 = 0x10f;
-        const u32 b = step;
-        const u32 f0 = b * EP_TB + q_t4;
-        const bool have = f0 < q_n;
-        u32 w[2] = {wcur.x, wcur.y};
-#pragma unroll
-        for (u32 q = 0; q < 2; q++)
-            w[q] = have ? w[q] : 0u;
-        wcur = fetchq(b + 2);
-        float x[4], f[4];
-        if (gain_off) {
-#pragma unroll
-            for (u32 q = 0; q < 2; q++) {
-                x[2 * q] = (float)(int)(int16_t)(w[q] & 0xffffu);
-                x[2 * q + 1] = (float)((int)w[q] >> 16);
-            }
-        } else {
-#pragma unroll
-            for (u32 q = 0; q < 2; q++) {
-                const u32 sg = pk_sign(w[q]);
-                const u32 aw = pk_sub(w[q] ^ sg, sg);
-                const u32 n0 = __umul24(aw & 0xffffu, q_g2);
-                const u32 n1 = __umul24(aw >> 16, q_g2);
-                const float m0 = (float)(__umulhi(n0, q_magic) >> q_shift);
-                const float m1 = (float)(__umulhi(n1, q_magic) >> q_shift);
-                const u32 b0 = (__builtin_bit_cast(u32, m0) & 0x7fffffffu) | ((w[q] << 16) & 0x80000000u);
-                const u32 b1 = (__builtin_bit_cast(u32, m1) & 0x7fffffffu) | (w[q] & 0x80000000u);
-                x[2 * q] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, b0), -32768.0f, 32767.0f);
-                x[2 * q + 1] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, b1), -32768.0f, 32767.0f);
-            }
-        }
-        const float p1 = dpp_f32<DPP_SHR1>(x[3]), p2 = dpp_f32<DPP_SHR1>(x[2]);
-        const float r1 = dpp_f32<DPP_SHL15>(qx1), r2 = dpp_f32<DPP_SHL15>(qx2);
-        const float xm1 = q_c == 0u ? r1 : p1;
-        const float xm2 = q_c == 0u ? r2 : p2;
-        qx1 = x[3];
-        qx2 = x[2];
-        f[0] = __builtin_fmaf(qc2, xm2, __builtin_fmaf(qc1, xm1, qc0 * x[0]));
-        f[1] = __builtin_fmaf(qc2, xm1, __builtin_fmaf(qc1, x[0], qc0 * x[1]));
-        f[2] = __builtin_fmaf(qc2, x[0], __builtin_fmaf(qc1, x[1], qc0 * x[2]));
-        f[3] = __builtin_fmaf(qc2, x[1], __builtin_fmaf(qc1, x[2], qc0 * x[3]));
-        *reinterpret_cast<float4 *>(lds + (b & 1u) * EP_TILE + q_r * EP_ROW + q_t4) = make_float4(f[0], f[1], f[2], f[3]);
     };
     // T-ff waves: feed-forward of the later sections, Y_k-1 -> F_k, for G / 2 rows in PASSES of
     // eight (each with the history registers of its own rows)
@@ -869,27 +756,9 @@ void k_eq_pipe(EqArgs a)
         for (u32 step = 0; step < nst2; step++)
             EQ_STEP(tff_step(step));
     } else {
-        if constexpr (UNEVEN) {
-            if (t_full) {                                 // beside a T-ff wave: 8 + 4 rows
-                for (u32 step = 0; step < nst2; step += 2) {
-                    EQ_STEP((tin_step(wa, step), tinq_step(qa, step)));
-                    EQ_STEP((tin_step(wb, step + 1), tinq_step(qb, step + 1)));
-                }
-            } else {                                      // beside an R wave: 4 rows
-                for (u32 step = 0; step < nst2; step += 2) {
-                    EQ_STEP(tinq_step(qa, step));
-                    EQ_STEP(tinq_step(qb, step + 1));
-                }
-            }
-            if (qkeep_n & 1u)
-                a.state[q_sidx].s[0][0] = qkeep1;
-            if (qkeep_n & 2u)
-                a.state[q_sidx].s[0][1] = qkeep2;
-        } else {
-            for (u32 step = 0; step < nst2; step += 2) {
-                EQ_STEP(tin_step(wa, step));
-                EQ_STEP(tin_step(wb, step + 1));
-            }
+        for (u32 step = 0; step < nst2; step += 2) {
+            EQ_STEP(tin_step(wa, step));
+            EQ_STEP(tin_step(wb, step + 1));
         }
         if (keep_n & 1u)
             a.state[l_sidx].s[0][0] = keep1;
