@@ -635,16 +635,6 @@ def main():
         out["small_blocks"] = sweep
     b.close()
 
-    # Several ranks: configs 4 and 5 at this N, outside the timed region and never part of `value` -- the
-    # driver's one command passes no --workload, and config 5's exchange is the only collective of the path.
-    if world > 1:
-        try:
-            out["node_vu"] = node_vu_legs(cm, shard, dist, rank, world, local_rank, rehearsal, NB)
-        except SystemExit:
-            raise
-        except Exception as e:                 # (every rank fails alike or the deadline of launch_ranks ends the run)
-            out["node_vu"] = {"error": "%s: %s" % (type(e).__name__, e)}
-
     def kernel_only(batch, frames, warm=100, timed=100):
         for _ in range(warm):
             batch.run(frames)
@@ -718,13 +708,68 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.workload, Cn)
 
+    # Several ranks: configs 4 and 5 at this N, after everything else of the line is known, outside the timed
+    # region and never part of `value` -- the driver's one command passes no --workload, and config 5's
+    # exchange is the only collective of the path.  Guarded: whatever happens in there, rank 0's line goes out.
+    printer = LinePrinter(rank, json_fd, out)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        guarded_legs(printer, dist, lambda: node_vu_legs(cm, shard, dist, rank, world, local_rank, rehearsal, NB))
     sys.stdout.flush()
-    if rank == 0:
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    os.close(json_fd)
+    printer.emit()
+
+
+class LinePrinter:
+    """rank 0's one JSON line, written exactly once -- by the main thread at the end of the run or by the
+    watchdog of guarded_legs() -- and never by another rank"""
+
+    def __init__(self, rank, json_fd, out):
+        import threading
+        self.rank, self.fd, self.out = rank, json_fd, out
+        self.lock = threading.Lock()
+        self.done = False
+
+    def emit(self):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            if self.rank == 0:
+                os.write(self.fd, (json.dumps(self.out) + "\n").encode())
+            os.close(self.fd)
+
+
+def guarded_legs(printer, dist, legs):
+    """The config-4 / config-5 legs hold the run's only data-path collective.  If a rank fails in there while its
+    peers wait inside a collective, nothing in the process would ever end the wait (gloo gives up after half an
+    hour, RCCL never): so every rank arms a watchdog around the legs and the closing barrier
+    ($COOLMIC_BENCH_LEGS_TIMEOUT_S, default 300).  When it fires, rank 0 writes its line -- complete but for
+    `node_vu`, which says what happened -- and every rank leaves the process."""
+    import threading
+    out = printer.out
+    limit = float(os.environ.get("COOLMIC_BENCH_LEGS_TIMEOUT_S", "300"))
+    dist.barrier()                             # (rank 0 has been busy with the extras of its line until here)
+
+    def fire():
+        out.setdefault("node_vu", {})
+        if "error" not in out["node_vu"]:
+            out["node_vu"] = {"error": "the config-4 / config-5 legs did not finish within %.0f s on rank %d "
+                                       "(a rank failed or a collective never completed); value and roofline above "
+                                       "are unaffected" % (limit, printer.rank)}
+        printer.emit()
+        os._exit(0)
+
+    dog = threading.Timer(limit, fire)
+    dog.daemon = True
+    dog.start()
+    try:
+        out["node_vu"] = legs()
+    except SystemExit:
+        raise
+    except Exception as e:
+        out["node_vu"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    dist.barrier()
+    dog.cancel()
+    dist.destroy_process_group()
 
 
 NODE_LEG_SHAPE = (8192, 1, 65536)      # configs 4 / 5 per GPU: 65 536 mono streams round-robin over 8 GPUs
@@ -861,11 +906,21 @@ def dry_run(args, rank, world, json_fd, shard):
         dist.all_gather(ranks, torch.tensor([rank, warm_steps]))
         out["ranks_seen"] = [int(r[0].item()) for r in ranks]
         out["warmup_steps_all_ranks"] = [int(r[1].item()) for r in ranks]
-        # the keys the real run's config-4 / config-5 legs report (node_vu_legs), no GPU work behind them here
-        out["node_vu"] = dict.fromkeys(NODE_VU_KEYS)
-        out["node_vu"]["rccl_ranks"] = 0
-        dist.barrier()
-        dist.destroy_process_group()
+
+        # the keys the real run's config-4 / config-5 legs report (node_vu_legs), no GPU work behind them here;
+        # through the same guard (test hook: a rank that never comes back from its legs)
+        def legs():
+            if os.environ.get("COOLMIC_BENCH_DRYRUN_LEGS_HANG_RANK") == str(rank):
+                time.sleep(3600)
+            flag = torch.tensor([rank], dtype=torch.int32)
+            dist.all_reduce(flag)              # (peers of a hanging rank wait here, as in a real collective)
+            d = dict.fromkeys(NODE_VU_KEYS)
+            d["rccl_ranks"] = 0
+            return d
+        printer = LinePrinter(rank, json_fd, out)
+        guarded_legs(printer, dist, legs)
+        printer.emit()
+        return
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)

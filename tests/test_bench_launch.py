@@ -63,6 +63,23 @@ def test_ranks_that_hang_are_ended_at_the_deadline():
     assert b"still running" in p.stderr and time.time() - t0 < 80
 
 
+def test_a_hang_inside_the_multi_rank_legs_cannot_lose_the_line():
+    """rank 1 never comes back from its config-4 / config-5 legs, rank 0 waits for it inside a collective: the
+    watchdog around the legs lets rank 0 write its line -- with node_vu saying what happened -- and ends every
+    rank; the launch succeeds, because value and roofline were measured before"""
+    import time
+    t0 = time.time()
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1"],
+             {"COOLMIC_BENCH_DRYRUN": "1", "COOLMIC_BENCH_DRYRUN_LEGS_HANG_RANK": "1",
+              "COOLMIC_BENCH_LEGS_TIMEOUT_S": "8"}, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and "did not finish within 8 s" in out["node_vu"]["error"]
+    assert time.time() - t0 < 60
+
+
 def test_no_self_launch_under_a_profiler_preload():
     p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1"],
              {"COOLMIC_BENCH_DRYRUN": "1", "ROCP_TOOL_LIBRARIES": "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"}, timeout=60)

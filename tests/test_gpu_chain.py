@@ -466,6 +466,52 @@ def test_equaliser_off_and_on_again_starts_from_silence(gpu, oracle):
     h.unref(); tr.unref()
 
 
+def test_meter_attached_to_a_transform_that_has_been_running(gpu, oracle):
+    """frames have flowed through the transform (and its device batch exists, with a partial frame carried)
+    before a meter is attached directly to its handle: the meter's window starts empty at the attachment,
+    shares the transform's launches from there (odd-sized upstream pieces: the carry path), and a re-attachment
+    in the middle of a window keeps the frames counted so far, as the reference's attach does
+    (ref: src/vumeter.c:101-110 touches nothing but the handle)"""
+    cm = gpu
+    C, frames = 2, 6000
+    x = oracle.lcg(77, frames * C)
+    src = cm.IoHandle.from_bytes(x.tobytes(), chunk=333)          # never a whole number of frames
+    tr = cm.Transform(48000, C)
+    assert tr.attach(src) == 0
+    src.unref()
+    assert tr.set_master_gain(2, 1000, [1500, 500]) == 0
+    _, g = oracle.gain(C, 2, 1000, [1500, 500])
+    want = oracle.gain_apply(g, x, C)
+    h = tr.get_iohandle()
+    n, d = h.read(1000)                                           # somebody reads before any meter exists
+    assert n == 1000 and np.array_equal(np.frombuffer(d, np.int16), want[:500])
+    pos = 1000
+    vu = cm.Vumeter(48000, C)
+    assert vu.attach(h) == 0 and vu.mode() == 1
+    v = oracle.vu_new(C)
+    for size in (-1, 100, 7, -1, 1024):
+        m = vu.read(size)
+        assert m >= 0 and m % (2 * C) == 0
+        oracle.vu_accumulate(v, want[pos // 2: (pos + m) // 2])
+        pos += m
+    # re-attach in the middle of the window: to a tee's reader handle over the same transform
+    tee = cm.Tee(1)
+    assert tee.attach(h) == 0
+    th = tee.get_iohandle(0)
+    assert vu.attach(th) == 0
+    th.unref()
+    for size in (-1, -1, 300):
+        m = vu.read(size)
+        assert m > 0
+        oracle.vu_accumulate(v, want[pos // 2: (pos + m) // 2])
+        pos += m
+    rc, r = vu.result()
+    _, ro = oracle.vu_result(v)
+    assert rc == 0 and r.as_dict() == of.vu_result_dict(ro)
+    for o in (h, vu, tee, tr):
+        o.unref()
+
+
 def test_meter_directly_on_a_transform_shares_its_launch(gpu, oracle):
     """A VU meter attached straight to a transform's handle lets the transform's launch accumulate
     the window (vumeter.c / transform.c, coolmic_transform_fuse_vu).  What the meter reports must
