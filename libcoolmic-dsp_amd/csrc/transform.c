@@ -157,6 +157,8 @@ static int rec_push(coolmic_transform_t *t, uint64_t off, uint32_t bytes, uint64
         t->rec_cap = cap;
         t->rec_head = 0;
     }
+    if (t->rec_count >= (1u << 16))    /* nobody consumes them (a meter that stopped reading): the oldest half goes */
+        rec_drop_front(t, t->rec_count / 2);
     r = rec_at_index(t, t->rec_count++);
     r->off = off;
     r->bytes = bytes;
