@@ -140,6 +140,15 @@ static transform_record_t *rec_at_index(coolmic_transform_t *t, size_t i)
     return &t->rec[(t->rec_head + i) % t->rec_cap];
 }
 
+static void rec_drop_front(coolmic_transform_t *t, size_t n)
+{
+    t->rec_head = (t->rec_head + n) % (t->rec_cap ? t->rec_cap : 1);
+    t->rec_count -= n;
+    t->rec_dropped += n;
+    if (t->rec_cursor < t->rec_dropped)
+        t->rec_cursor = t->rec_dropped;
+}
+
 static int rec_push(coolmic_transform_t *t, uint64_t off, uint32_t bytes, uint64_t seq)
 {
     transform_record_t *r;
@@ -193,15 +202,6 @@ static int rec_fetch_all(coolmic_transform_t *t)
     free(tmp);
     t->rec_fetched_seq = next;
     return 0;
-}
-
-static void rec_drop_front(coolmic_transform_t *t, size_t n)
-{
-    t->rec_head = (t->rec_head + n) % (t->rec_cap ? t->rec_cap : 1);
-    t->rec_count -= n;
-    t->rec_dropped += n;
-    if (t->rec_cursor < t->rec_dropped)
-        t->rec_cursor = t->rec_dropped;
 }
 
 /* whole frames through the GPU, in place.  `off`: where these bytes lie in the handle's output.  0 on success. */
