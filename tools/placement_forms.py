@@ -43,7 +43,10 @@ F32 = cm.OUT_F32 if os.environ.get("PF_F32") else 0            # float planes be
 forms = [("NW=%s" % n, make(cm.VU if RO else cm.OUT_PCM | cm.VU | F32, ("CMHIP_FAST_NW", n))) for n in (("1", "4", "8") if Cn <= 2 else ("1",))]
 if not RO:
     forms.insert(1, ("no window", make(cm.OUT_PCM | F32)))
-for extra in sys.argv[3:]:                # other builds of the library (timing-only variants), on the same arrays
+    if SNAP and Cn <= 2:                     # the four-wave form with every launch merging by atomics (round 2)
+        forms.insert(3, ("NW=4 atomics", make(cm.OUT_PCM | cm.VU | F32, ("CMHIP_WINDOW_RECORDS", "0"))))
+for extra in sys.argv[3:]:                # other builds of the library (timing-only variants), on the same arrays; PF_SNAP=1: a
+VU window per launch, where the four-wave form stores window records instead of issuing atomics
     import importlib.util
     os.environ["COOLMIC_HIP_LIB"] = os.path.abspath(extra)
     tag = "cm_x%d" % len(forms)
@@ -67,14 +70,24 @@ for a in arr[1:]:
 ins, outs = arr[0::2], arr[1::2]
 
 
+SNAP = bool(os.environ.get("PF_SNAP"))          # a VU window per launch (snapshot + collect every step), as bench.py runs
+
+
+def step(b, pi, po):
+    b.run_slots(T, pi, po)
+    if SNAP and (b.flags & cm.VU):
+        b.vu_snapshot()
+        b.vu_collect()
+
+
 def timed(b, pi, po, warm=6, n=30):
     for _ in range(warm):
-        b.run_slots(T, pi, po)
+        step(b, pi, po)
     b.sync()
     b.timing(True)
     b.timing_read()
     for _ in range(n):
-        b.run_slots(T, pi, po)
+        step(b, pi, po)
     ms, k = b.timing_read()
     b.timing(False)
     return ms / k
