@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """{window merged by workgroups of 1, 4, 8, 16 waves; no window} x {input and output arrays of the same placement class, of different
-ones}: the config-2 kernel in one process, on the slowest and the fastest of N x N array pairs."""
+ones}: the config-2 kernel in one process, on the slowest and the fastest of N x N array pairs.
+PF_SNAP=1: a VU window per launch (snapshot + collect every step, as bench.py runs), where the four-wave form stores
+window records instead of issuing atomics; "NW=4 atomics" is then that form with CMHIP_WINDOW_RECORDS=0."""
 import ctypes as C
 import importlib
 import os
@@ -38,6 +40,7 @@ def make(flags, env=None):
     return b
 
 
+SNAP = bool(os.environ.get("PF_SNAP"))          # a VU window per launch (snapshot + collect every step), as bench.py runs
 RO = len(sys.argv) > 2 and sys.argv[2] == "ro"          # the read-only runs (VU only): no output array, no pairs
 F32 = cm.OUT_F32 if os.environ.get("PF_F32") else 0            # float planes beside the PCM result
 forms = [("NW=%s" % n, make(cm.VU if RO else cm.OUT_PCM | cm.VU | F32, ("CMHIP_FAST_NW", n))) for n in (("1", "4", "8") if Cn <= 2 else ("1",))]
@@ -45,8 +48,7 @@ if not RO:
     forms.insert(1, ("no window", make(cm.OUT_PCM | F32)))
     if SNAP and Cn <= 2:                     # the four-wave form with every launch merging by atomics (round 2)
         forms.insert(3, ("NW=4 atomics", make(cm.OUT_PCM | cm.VU | F32, ("CMHIP_WINDOW_RECORDS", "0"))))
-for extra in sys.argv[3:]:                # other builds of the library (timing-only variants), on the same arrays; PF_SNAP=1: a
-VU window per launch, where the four-wave form stores window records instead of issuing atomics
+for extra in sys.argv[3:]:                # other builds of the library (timing-only variants), on the same arrays
     import importlib.util
     os.environ["COOLMIC_HIP_LIB"] = os.path.abspath(extra)
     tag = "cm_x%d" % len(forms)
@@ -68,9 +70,6 @@ hip.hipMemcpy(arr[0], host.ctypes.data, BYTES, 1)
 for a in arr[1:]:
     hip.hipMemcpy(a, arr[0], BYTES, 3)
 ins, outs = arr[0::2], arr[1::2]
-
-
-SNAP = bool(os.environ.get("PF_SNAP"))          # a VU window per launch (snapshot + collect every step), as bench.py runs
 
 
 def step(b, pi, po):
