@@ -194,15 +194,6 @@ struct cmhip_batch {
     // k_vu_pack writes itself (h_pack / d_pack: host / device view)
     unsigned long long *h_pack[3], *d_pack[3];
     unsigned int snap_set2[3];             // which of the three window sets the snapshot closed (its event: ev_reset)
-    // Window records (RunArgs::rec): the FIRST launch of a window -- the only one, for a host that closes a
-    // window per block -- stores its workgroups' window sums in a record array of the window's set instead of
-    // adding them to the windows with device-scope atomics (those cost the config-2 kernel 4-5 %); whoever reads
-    // the set folds the records in (k_vu_pack, k_node_partial; k_vu_fold before a direct read).
-    unsigned long long *d_rec[3];          // per window set: [S][rec_cap][2C] words, allocated on first use
-    uint32_t rec_cap;                      // records per stream the arrays hold (a full slot's workgroups)
-    bool rec_live[3];                      // the set's window has records of its first launch ...
-    uint32_t rec_groups[3];                // ... this many per stream
-    uint32_t win_runs[3];                  // launches accounted to the set's window since it was opened
     bool collecting;                       // between cmhip_batch_vu_collect_begin and _end
     coolmic_vumeter_result_t *job_out;
     int *job_rc;
@@ -249,8 +240,6 @@ static RunTune read_tune()
     }
     if (getenv("CMHIP_PLACE_DEBUG"))
         t.place_debug = 1;
-    if (const char *e = getenv("CMHIP_WINDOW_RECORDS"))
-        t.rec_off = atoi(e) == 0 ? 1u : 0u;
     return t;
 }
 
@@ -366,8 +355,6 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     (void)hipFree(b->d_eqstate);
     (void)hipFree(b->d_sink);
     (void)hipFree(b->d_node_scratch);
-    for (int i = 0; i < 3; i++)
-        (void)hipFree(b->d_rec[i]);
     (void)hipFree(b->d_ring);
     if (b->h_ring)
         (void)hipHostFree(b->h_ring);
@@ -769,13 +756,6 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->h_pack[0] = b->h_pack[1] = b->h_pack[2] = nullptr;
     b->d_pack[0] = b->d_pack[1] = b->d_pack[2] = nullptr;
     b->snap_set2[0] = b->snap_set2[1] = b->snap_set2[2] = 0;
-    for (int i = 0; i < 3; i++) {
-        b->d_rec[i] = nullptr;
-        b->rec_live[i] = false;
-        b->rec_groups[i] = 0;
-        b->win_runs[i] = 0;
-    }
-    b->rec_cap = 0;
     b->collecting = false;
     b->job_out = nullptr;
     b->job_rc = nullptr;
@@ -1237,18 +1217,6 @@ static int settle_node(cmhip_batch_t *b)
     return COOLMIC_ERROR_NONE;
 }
 
-// the main stream is about to read the current windows straight from device memory: records of the window's
-// first launch go into the VuState first
-static int settle_records(cmhip_batch_t *b)
-{
-    const unsigned i = b->cur;
-    if (b->rec_live[i]) {
-        HIP_TRY(launch_vu_fold(b->d_vu2[i], b->d.streams, b->d.channels, b->d_rec[i], b->rec_groups[i], b->stream));
-        b->rec_live[i] = false;
-    }
-    return COOLMIC_ERROR_NONE;
-}
-
 static int flush_params(cmhip_batch_t *b)
 {
     if (b->param_dirty) {
@@ -1403,26 +1371,6 @@ static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per
         a.parity = parity;
         a.done_flag = flag;
         a.done_seq = flag_seq;
-        // window records for the first launch of a window (many streams in HBM; the one-stream batches of the
-        // operator stages read their windows directly and would pay a fold launch per result)
-        uint32_t groups = 0;
-        if (vu && !ring && !b->tune.rec_off && b->win_runs[b->cur] == 0 && !b->h_in && b->d.streams >= 256 &&
-            run_writes_records(a, b->tune, &groups)) {
-            const unsigned i = b->cur;
-            if (!b->d_rec[i]) {
-                RunArgs full = a;
-                full.frames = (uint32_t)b->d.max_frames;
-                uint32_t cap = 0;
-                (void)run_writes_records(full, b->tune, &cap);
-                b->rec_cap = cap;
-                HIP_TRY(hipMalloc((void **)&b->d_rec[i], (size_t)b->d.streams * cap * 2u * b->d.channels * sizeof(unsigned long long)));
-            }
-            if (groups <= b->rec_cap) {
-                a.rec = b->d_rec[i];
-                b->rec_live[i] = true;
-                b->rec_groups[i] = groups;
-            }
-        }
         HIP_TRY(launch_run(a, b->tune, b->stream, ev.a, ev.b, &flagged));
         b->in_flight = true;
     }
@@ -1430,12 +1378,10 @@ static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per
     if (timed)
         b->ev_used.push_back(ev);
     g_runs.fetch_add(1, std::memory_order_relaxed);
-    if (ring) {
+    if (ring)
         b->ring_seq++;
-    } else if (vu) {
+    else if (vu)
         b->parity ^= 1u;                   // the kernel wrote the other samples slot
-        b->win_runs[b->cur]++;
-    }
     return COOLMIC_ERROR_NONE;
 }
 
@@ -1527,7 +1473,7 @@ extern "C" int cmhip_batch_vu_result(cmhip_batch_t *b, unsigned int stream,
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     b->last_done = nullptr;                  // main-stream work on the windows follows the last run
-    if (settle_node(b) || settle_records(b))
+    if (settle_node(b))
         return COOLMIC_ERROR_GENERIC;
     VuState v;
     HIP_TRY(hipMemcpyAsync(&v, b->d_vu + stream, sizeof(v), hipMemcpyDeviceToHost, b->stream));
@@ -1565,9 +1511,7 @@ extern "C" int cmhip_batch_vu_snapshot(cmhip_batch_t *b)
         HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_main, 0));
     }
     HIP_TRY(launch_vu_pack(b->d_vu2[i], b->d.streams, b->d.channels, b->parity, b->d_pack[slot], b->copy_stream,
-                           b->ev_reset[i], b->rec_live[i] ? b->d_rec[i] : nullptr, b->rec_groups[i]));
-    b->rec_live[i] = false;                  // (folded; the set's next window starts anew)
-    b->win_runs[i] = 0;
+                           b->ev_reset[i]));
     b->snap_set2[slot] = i;
     b->reset_pending[i] = true;
     b->cur = (i + 1u) % 3u;
@@ -1669,14 +1613,12 @@ extern "C" int cmhip_batch_vu_reset(cmhip_batch_t *b, long stream)
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     b->last_done = nullptr;                  // main-stream work on the windows follows the last run
-    if (settle_node(b) || settle_records(b))
+    if (settle_node(b))
         return COOLMIC_ERROR_GENERIC;
-    if (stream < 0) {
+    if (stream < 0)
         HIP_TRY(hipMemsetAsync(b->d_vu, 0, b->d.streams * sizeof(VuState), b->stream));
-        b->win_runs[b->cur] = 0;             // every window of the set is empty again
-    } else {
+    else
         HIP_TRY(hipMemsetAsync(b->d_vu + stream, 0, sizeof(VuState), b->stream));
-    }
     return COOLMIC_ERROR_NONE;
 }
 
@@ -1689,7 +1631,7 @@ extern "C" int cmhip_batch_vu_raw(cmhip_batch_t *b, unsigned int stream, int64_t
         return fail(COOLMIC_ERROR_INVAL, "vu_raw: stream out of range");
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
-    if (settle_node(b) || settle_records(b))
+    if (settle_node(b))
         return COOLMIC_ERROR_GENERIC;
     VuState v;
     HIP_TRY(hipMemcpyAsync(&v, b->d_vu + stream, sizeof(v), hipMemcpyDeviceToHost, b->stream));
@@ -1780,7 +1722,7 @@ extern "C" CMHIP_INTERNAL int cmhip_batch_vu_raw_state(cmhip_batch_t *b, unsigne
         return fail(COOLMIC_ERROR_FAULT, "vu_raw_state: NULL argument");
     if (stream >= b->d.streams || !(b->d.flags & CMHIP_VU))
         return fail(COOLMIC_ERROR_INVAL, "vu_raw_state: stream out of range or batch without VU");
-    if (use(b) || settle_node(b) || settle_records(b))
+    if (use(b) || settle_node(b))
         return COOLMIC_ERROR_GENERIC;
     VuState v;
     HIP_TRY(hipMemcpyAsync(&v, b->d_vu + stream, sizeof(v), hipMemcpyDeviceToHost, b->stream));
@@ -1880,8 +1822,7 @@ int cmhip_batch_node_partial_split(cmhip_batch_t *b, long long *dst_sum, long lo
     b->done_next = (b->done_next + 1u) & 3u;
     b->last_done = nullptr;
     HIP_TRY(launch_node_partial(b->d_vu, b->d.streams, b->d.channels, b->parity, first_global, global_step,
-                                dst_sum, dst_key, clear != 0, b->stream, done,
-                                b->rec_live[b->cur] ? b->d_rec[b->cur] : nullptr, b->rec_groups[b->cur]));
+                                dst_sum, dst_key, clear != 0, b->stream, done));
     b->last_done = done;
     return COOLMIC_ERROR_NONE;
 }
@@ -1902,8 +1843,7 @@ int cmhip_batch_node_partial_side(cmhip_batch_t *b, long long *dst_sum, long lon
         HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_main, 0));
     }
     HIP_TRY(launch_node_partial(b->d_vu, b->d.streams, b->d.channels, b->parity, first_global, global_step,
-                                dst_sum, dst_key, false, b->copy_stream, nullptr,
-                                b->rec_live[b->cur] ? b->d_rec[b->cur] : nullptr, b->rec_groups[b->cur]));
+                                dst_sum, dst_key, false, b->copy_stream, nullptr));
     b->node_reading = true;
     return COOLMIC_ERROR_NONE;
 }

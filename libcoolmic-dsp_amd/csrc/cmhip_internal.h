@@ -90,11 +90,6 @@ struct RunArgs {
     // when the grid has more than one workgroup.
     uint32_t      *done_flag;
     uint32_t       done_seq;
-    // Window records instead of atomics (the mono / stereo form that writes PCM, four waves per workgroup): when
-    // not null, a workgroup's last wave STORES its sums and keys -- C + C words at rec[blockIdx.x * 2C] -- instead
-    // of adding them to the stream's window with device-scope atomics; whoever closes the window folds the
-    // records in.  Only for the first launch of a window, every stream at its full count.
-    unsigned long long *rec;
 };
 
 // Tuning knobs of the block kernels' launcher, read from the environment ONCE, when a batch is
@@ -108,7 +103,6 @@ struct RunTune {
     int32_t  place_env;            // CMHIP_PLACE: -1 unset (only batches created with CMHIP_PLACE_SEARCH search), 0 never,
                                    // 1 the first large batch of a device also without the flag, 2 every large batch
     uint32_t place_debug;          // CMHIP_PLACE_DEBUG: the probe times of the placement search on stderr
-    uint32_t rec_off;              // CMHIP_WINDOW_RECORDS=0: every launch merges its window sums with atomics (A/B)
 };
 
 struct EqArgs {
@@ -154,20 +148,13 @@ hipError_t prepare_eq(int device);
 hipError_t launch_eq(const EqArgs &a, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
                      bool *flagged = nullptr);
 hipError_t launch_generate(const GenArgs &a, int mode, hipStream_t st);
-// (rec / rec_groups: the window records of the set's first launch, RunArgs::rec, or nullptr)
 hipError_t launch_node_partial(const VuState *vu, uint32_t streams, uint32_t channels,
                                uint32_t parity, uint64_t first_global, uint64_t global_step,
                                long long *dst_sum, long long *dst_key, bool clear, hipStream_t st,
-                               hipEvent_t ev_stop = nullptr, const unsigned long long *rec = nullptr,
-                               uint32_t rec_groups = 0);
+                               hipEvent_t ev_stop = nullptr);
 // (a set of windows -> [1 + 2C][streams] words in pinned, device-mapped host memory; clears the set)
 hipError_t launch_vu_pack(VuState *vu, uint32_t streams, uint32_t channels, uint32_t parity,
-                          unsigned long long *dst_host_mapped, hipStream_t st, hipEvent_t ev_stop,
-                          const unsigned long long *rec = nullptr, uint32_t rec_groups = 0);
-hipError_t launch_vu_fold(VuState *vu, uint32_t streams, uint32_t channels, const unsigned long long *rec,
-                          uint32_t rec_groups, hipStream_t st);
-// does launch_run() write window records for these arguments (RunArgs::rec set), and how many per stream
-bool run_writes_records(const RunArgs &a, const RunTune &tune, uint32_t *groups);
+                          unsigned long long *dst_host_mapped, hipStream_t st, hipEvent_t ev_stop);
 hipError_t launch_ceiling(int mode, const void *src, void *dst, size_t bytes,
                           unsigned long long *sink, hipStream_t st);
 

@@ -336,16 +336,10 @@ __device__ __forceinline__ void run_fast(const RunArgs &a)
         asm volatile("" ::: "memory");
         if (n == (u32)NW - 1u && lane < (u32)C) {
             const u64 ssum = shared_.sum[lane], skey = shared_.key[lane];
-            if (a.rec) {                         // (uniform) a record of this workgroup's own: plain stores
-                u64 *r = a.rec + (u64)blockIdx.x * (2u * (u32)C);
-                r[lane] = ssum;
-                r[(u32)C + lane] = skey;
-            } else {
-                if (ssum)
-                    atomicAdd(&vs->power[lane], ssum);
-                if (skey)
-                    atomicMax(&vs->key[lane], skey);
-            }
+            if (ssum)
+                atomicAdd(&vs->power[lane], ssum);
+            if (skey)
+                atomicMax(&vs->key[lane], skey);
         }
     }
 }
@@ -940,20 +934,6 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
 
 constexpr u32 FAST_NW = 4;
 
-// the form that writes window records (RunArgs::rec): mono / stereo, PCM + VU, four waves per workgroup
-bool run_writes_records(const RunArgs &a, const RunTune &tune, uint32_t *groups)
-{
-    const bool pcm = a.out != nullptr, f32 = a.f32 != nullptr, vu = a.vu != nullptr;
-    const u32 nw = tune.fast_nw ? tune.fast_nw : FAST_NW;
-    if (a.channels > 2 || !pcm || f32 || !vu || nw != 4u || a.nframes || a.frames == 0)
-        return false;
-    const u64 nvec = ((u64)a.frames * a.channels + 7) / 8;
-    const u32 chunks = (u32)((nvec + 64ull * TILE_U - 1) / (64ull * TILE_U));
-    if (groups)
-        *groups = ((chunks ? chunks : 1u) + nw - 1u) / nw;
-    return true;
-}
-
 hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop,
                       bool *flagged)
 {
@@ -997,8 +977,6 @@ hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hip
         if ((u64)a.streams * ((b.chunks + nw - 1u) / nw) >= (1ull << 31))
             return hipErrorInvalidValue;
         flag_if_single(b, (pcm && !f32 && vu && nw > 1u) ? gridw : grid);
-        if (!(pcm && !f32 && vu && nw == 4u))
-            b.rec = nullptr;                     // (only that form writes window records)
 #define CMHIP_FAST(C, P, F, V, U)                                                  \
     hipExtLaunchKernelGGL((k_run_fast<C, P, F, V, U>), dim3(grid), dim3(64), 0, st, ev_start, ev_stop, 0, b)
 #define CMHIP_FAST_W(C, P, F, V, U)                                                \

@@ -113,35 +113,10 @@ __device__ __forceinline__ u64 wave_max(u64 v)
 // mono or stereo batch fills two or three of them, and the kernel runs beside the batch's next run, where
 // every instruction it does not execute counts (config 5: 17 slots reduced for one channel took 30-300 us
 // there instead of 9 alone).  One wave per workgroup: it takes whatever slot a CU has free.
-// What a stream's window holds beside its VuState: the records of the window's first launch, when that launch
-// stored its workgroups' sums instead of adding them with atomics (RunArgs::rec): `groups` records of C sums and
-// C keys per stream, rec[(stream * groups + g) * 2C + ...].  Everybody who reads a window folds them in.
-struct WinRec {
-    const u64 *rec;                              // nullptr: none
-    u32 groups;
-};
-template <u32 NC>
-__device__ __forceinline__ void fold_records(const WinRec &w, u32 s, u32 channels, u64 (&power)[NC], u64 (&key)[NC])
-{
-    if (!w.rec)
-        return;
-    const u64 *r = w.rec + (u64)s * w.groups * (2u * channels);
-    for (u32 g = 0; g < w.groups; g++, r += 2u * channels) {
-#pragma unroll
-        for (u32 c = 0; c < NC; c++) {
-            if (c < channels) {
-                power[c] += r[c];
-                const u64 k = r[channels + c];
-                key[c] = k > key[c] ? k : key[c];
-            }
-        }
-    }
-}
-
 template <u32 NC>
 __global__ __launch_bounds__(64) void k_node_partial(const VuState *vu, u32 streams, u32 channels,
                                                      u32 parity, u64 first_global, u64 global_step,
-                                                     long long *dst_sum, long long *dst_key, WinRec wr)
+                                                     long long *dst_sum, long long *dst_key)
 {
     u64 sum[NC + 1], key[NC + 1];                // [NC]: frames / the peak over all channels
 #pragma unroll
@@ -152,18 +127,11 @@ __global__ __launch_bounds__(64) void k_node_partial(const VuState *vu, u32 stre
     for (u32 s = blockIdx.x * 64u + threadIdx.x; s < streams; s += gridDim.x * 64u) {
         const u64 gs = first_global + (u64)s * global_step;
         sum[NC] += NC == 1 ? vu[s].samples[parity] : vu[s].samples[parity] / channels;
-        u64 wp[NC], wk[NC];
-#pragma unroll
-        for (u32 c = 0; c < NC; c++) {
-            wp[c] = c < channels ? vu[s].power[c] : 0;
-            wk[c] = c < channels ? vu[s].key[c] : 0;
-        }
-        fold_records<NC>(wr, s, channels, wp, wk);
 #pragma unroll
         for (u32 c = 0; c < NC; c++) {
             if (c < channels) {
-                sum[c] += wp[c];
-                const u64 k0 = wk[c];
+                sum[c] += vu[s].power[c];
+                const u64 k0 = vu[s].key[c];
                 if (k0) {
                     const u64 mag = k0 >> KEY_ABS_SHIFT;
                     const u64 idx = ~(k0 >> 1) & KEY_IDX_MASK;
@@ -193,10 +161,8 @@ __global__ __launch_bounds__(64) void k_node_partial(const VuState *vu, u32 stre
 
 hipError_t launch_node_partial(const VuState *vu, u32 streams, u32 channels, u32 parity,
                                uint64_t first_global, uint64_t global_step, long long *dst_sum,
-                               long long *dst_key, bool clear, hipStream_t st, hipEvent_t ev_stop,
-                               const unsigned long long *rec, u32 rec_groups)
+                               long long *dst_key, bool clear, hipStream_t st, hipEvent_t ev_stop)
 {
-    const WinRec wr = {rec, rec_groups};
     if (clear) {                                 // (a cmhip_node_t clears a whole record set at once instead)
         hipError_t e = hipMemsetAsync(dst_sum, 0, sizeof(long long) * (MAX_CH + 1), st);
         if (e != hipSuccess)
@@ -210,13 +176,13 @@ hipError_t launch_node_partial(const VuState *vu, u32 streams, u32 channels, u32
         grid = 1024;
     if (channels == 1)
         hipExtLaunchKernelGGL(k_node_partial<1>, dim3(grid), dim3(64), 0, st, nullptr, ev_stop, 0, vu, streams, channels,
-                              parity, first_global, global_step, dst_sum, dst_key, wr);
+                              parity, first_global, global_step, dst_sum, dst_key);
     else if (channels == 2)
         hipExtLaunchKernelGGL(k_node_partial<2>, dim3(grid), dim3(64), 0, st, nullptr, ev_stop, 0, vu, streams, channels,
-                              parity, first_global, global_step, dst_sum, dst_key, wr);
+                              parity, first_global, global_step, dst_sum, dst_key);
     else
         hipExtLaunchKernelGGL(k_node_partial<MAX_CH>, dim3(grid), dim3(64), 0, st, nullptr, ev_stop, 0, vu, streams,
-                              channels, parity, first_global, global_step, dst_sum, dst_key, wr);
+                              channels, parity, first_global, global_step, dst_sum, dst_key);
     return hipGetLastError();
 }
 
@@ -227,25 +193,18 @@ hipError_t launch_node_partial(const VuState *vu, u32 streams, u32 channels, u32
 // instruction, whole lines over PCIe), and the device copy cleared for the set's next turn.  One launch on
 // the copy stream replaces a 264 B-per-stream copy, a clear of the same size and two event records.
 template <u32 NC>
-__global__ __launch_bounds__(64) void k_vu_pack(VuState *vu, u32 streams, u32 channels, u32 parity, u64 *dst, WinRec wr)
+__global__ __launch_bounds__(64) void k_vu_pack(VuState *vu, u32 streams, u32 channels, u32 parity, u64 *dst)
 {
     const u32 s = blockIdx.x * 64u + threadIdx.x;
     if (s >= streams)
         return;
     VuState *v = vu + s;
     dst[s] = v->samples[parity];
-    u64 wp[NC], wk[NC];
-#pragma unroll
-    for (u32 c = 0; c < NC; c++) {
-        wp[c] = c < channels ? v->power[c] : 0;
-        wk[c] = c < channels ? v->key[c] : 0;
-    }
-    fold_records<NC>(wr, s, channels, wp, wk);
 #pragma unroll
     for (u32 c = 0; c < NC; c++) {
         if (c < channels) {
-            dst[(u64)(1u + c) * streams + s] = wp[c];
-            dst[(u64)(1u + channels + c) * streams + s] = wk[c];
+            dst[(u64)(1u + c) * streams + s] = v->power[c];
+            dst[(u64)(1u + channels + c) * streams + s] = v->key[c];
             v->power[c] = 0;
             v->key[c] = 0;
         }
@@ -255,53 +214,18 @@ __global__ __launch_bounds__(64) void k_vu_pack(VuState *vu, u32 streams, u32 ch
 }
 
 hipError_t launch_vu_pack(VuState *vu, u32 streams, u32 channels, u32 parity, unsigned long long *dst_host_mapped,
-                          hipStream_t st, hipEvent_t ev_stop, const unsigned long long *rec, u32 rec_groups)
+                          hipStream_t st, hipEvent_t ev_stop)
 {
     const u32 grid = (streams + 63u) / 64u;
-    const WinRec wr = {rec, rec_groups};
     if (channels == 1)
         hipExtLaunchKernelGGL(k_vu_pack<1>, dim3(grid), dim3(64), 0, st, nullptr, ev_stop, 0, vu, streams, channels, parity,
-                              dst_host_mapped, wr);
+                              dst_host_mapped);
     else if (channels == 2)
         hipExtLaunchKernelGGL(k_vu_pack<2>, dim3(grid), dim3(64), 0, st, nullptr, ev_stop, 0, vu, streams, channels, parity,
-                              dst_host_mapped, wr);
+                              dst_host_mapped);
     else
         hipExtLaunchKernelGGL(k_vu_pack<MAX_CH>, dim3(grid), dim3(64), 0, st, nullptr, ev_stop, 0, vu, streams, channels,
-                              parity, dst_host_mapped, wr);
-    return hipGetLastError();
-}
-
-// The records of a window's first launch folded into its VuState, for whoever reads a window straight from
-// device memory (the per-stream result of the operator stages, cmhip_batch_vu_raw): afterwards the window is
-// what it would be had that launch used atomics.
-__global__ __launch_bounds__(64) void k_vu_fold(VuState *vu, u32 streams, u32 channels, WinRec wr)
-{
-    const u32 s = blockIdx.x * 64u + threadIdx.x;
-    if (s >= streams)
-        return;
-    u64 wp[2], wk[2];
-#pragma unroll
-    for (u32 c = 0; c < 2; c++) {
-        wp[c] = c < channels ? vu[s].power[c] : 0;
-        wk[c] = c < channels ? vu[s].key[c] : 0;
-    }
-    fold_records<2>(wr, s, channels, wp, wk);
-#pragma unroll
-    for (u32 c = 0; c < 2; c++) {
-        if (c < channels) {
-            vu[s].power[c] = wp[c];
-            vu[s].key[c] = wk[c];
-        }
-    }
-}
-
-hipError_t launch_vu_fold(VuState *vu, u32 streams, u32 channels, const unsigned long long *rec, u32 rec_groups,
-                          hipStream_t st)
-{
-    if (channels > 2u)
-        return hipErrorInvalidValue;             // (only the mono / stereo form writes records)
-    const WinRec wr = {rec, rec_groups};
-    hipLaunchKernelGGL(k_vu_fold, dim3((streams + 63u) / 64u), dim3(64), 0, st, vu, streams, channels, wr);
+                              parity, dst_host_mapped);
     return hipGetLastError();
 }
 

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """{window merged by workgroups of 1, 4, 8, 16 waves; no window} x {input and output arrays of the same placement class, of different
 ones}: the config-2 kernel in one process, on the slowest and the fastest of N x N array pairs.
-PF_SNAP=1: a VU window per launch (snapshot + collect every step, as bench.py runs), where the four-wave form stores
-window records instead of issuing atomics; "NW=4 atomics" is then that form with CMHIP_WINDOW_RECORDS=0."""
+PF_SNAP=1: a VU window per launch (snapshot + collect every step, as bench.py runs)."""
 import ctypes as C
 import importlib
 import os
@@ -46,8 +45,6 @@ F32 = cm.OUT_F32 if os.environ.get("PF_F32") else 0            # float planes be
 forms = [("NW=%s" % n, make(cm.VU if RO else cm.OUT_PCM | cm.VU | F32, ("CMHIP_FAST_NW", n))) for n in (("1", "4", "8") if Cn <= 2 else ("1",))]
 if not RO:
     forms.insert(1, ("no window", make(cm.OUT_PCM | F32)))
-    if SNAP and Cn <= 2:                     # the four-wave form with every launch merging by atomics (round 2)
-        forms.insert(3, ("NW=4 atomics", make(cm.OUT_PCM | cm.VU | F32, ("CMHIP_WINDOW_RECORDS", "0"))))
 for extra in sys.argv[3:]:                # other builds of the library (timing-only variants), on the same arrays
     import importlib.util
     os.environ["COOLMIC_HIP_LIB"] = os.path.abspath(extra)
