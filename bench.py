@@ -350,21 +350,7 @@ def main():
     setup = {"placement_search": "on (bench.py passes CMHIP_PLACE_SEARCH; the library's default is off)"
              if place_search else "off"}
     if place_search:
-        t_c = time.perf_counter()
-        a0 = make_batch()
-        setup["batch_create_ms_place_off"] = round((time.perf_counter() - t_c) * 1e3, 1)
-        t_w0 = time.perf_counter()
-        while time.perf_counter() - t_w0 < MIN_WARMUP_S:
-            for _ in range(16):
-                a0.run(T)
-            a0.sync()
-        a0.timing(True)
-        a0.timing_read()
-        for _ in range(64):
-            a0.run(T)
-        ms0, n0 = a0.timing_read()
-        setup["kernel_avg_ms_place_off"] = round(ms0 / max(n0, 1), 4)
-        a0.close()
+        setup.update(place_off_leg(make_batch, T))
     t_c = time.perf_counter()
     b = make_batch(cm.PLACE_SEARCH if place_search else 0)
     setup["batch_create_ms"] = round((time.perf_counter() - t_c) * 1e3, 1)
@@ -481,21 +467,7 @@ def main():
 
     kern_avg_ms = kern_ms / max(launches, 1)
     achieved = samples_per_step_rank * bps / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
-    # HBM bytes per launch: NOT measured in this run -- PMC counters need rocprofv3 passes of their
-    # own (tools/hbm_pmc.sh: FETCH_SIZE and WRITE_SIZE separately, FETCH_SIZE doubled for gfx950);
-    # the figure is read from the committed summary of such a run on the same workload and labelled
-    traffic = traffic_source = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
-    if os.path.exists(pmc_path):
-        try:
-            pmc = json.load(open(pmc_path))
-            if pmc.get("workload") == args.workload and pmc.get("frames") == T and \
-                    pmc.get("streams") == S:
-                traffic = pmc.get("hbm_bytes_per_launch")
-                traffic_source = "profiles/pmc_%s.json (%s; separate rocprofv3 --pmc passes, not this run)" % (
-                    args.workload, pmc.get("round", "round 1"))
-        except Exception:
-            traffic = traffic_source = None
+    traffic, traffic_source = traffic_from_profiles(args.workload, S, T)
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
@@ -567,140 +539,15 @@ def main():
             pass
 
     if rank == 0 and not args.no_extras and not eq:
-        extras = {}
-        try:
-            extras["hbm_read_ceiling_GBs"] = round(b.ceiling(0, 10), 1)
-            extras["hbm_copy_ceiling_GBs"] = round(b.ceiling(1, 10), 1)
-            # the kernel against the measured ceilings as well as against the nominal peak
-            # (PCM materialised: the copy with the same access shape; read-only runs: the read ceiling)
-            if extras["hbm_copy_ceiling_GBs"] > 0:
-                extras["kernel_frac_of_copy_ceiling"] = round(achieved / extras["hbm_copy_ceiling_GBs"], 4)
-        except Exception as e:           # measurement extras must not break the line
-            extras["ceiling_error"] = str(e)
-        out["measured_ceilings"] = extras
-        # the small-block regime, same batch, fewer frames per launch.  Per block size the kernel
-        # alone, the whole STEP with a VU window per block (launch + packed snapshot + host dB finish of all
-        # windows, as in the timed region), and the step when windows close every 20 blocks -- the reference's
-        # own granularity (a result every 20 reads, ref: src/simple.c:370)
-        sweep = {}
-        try:
-            for frames in (512, 2880, 4096):
-                if frames >= T:
-                    continue
-                b.vu_reset(-1)
-                for _ in range(3):
-                    b.run(frames)
-                b.sync()
-                b.timing(True)
-                b.timing_read()
-                for _ in range(20):
-                    b.run(frames)
-                ms, n = b.timing_read()
-                b.timing(False)
-                entry = {"kernel_avg_ms": round(ms / n, 4),
-                         "achieved_GBs": round(S * Cn * frames * bps / (ms / n * 1e-3) / 1e9, 1)}
-                for every, key in ((1, "step_ms_window_per_block"), (20, "step_ms_window_per_20_blocks")):
-                    def loop(nsteps):
-                        # the dB finish of window k-1 runs on the helper threads beside launch and snapshot of
-                        # block k+1 (cmhip_batch_vu_collect_begin / _end); up to three snapshots are pending
-                        collecting, waiting = False, 0
-                        for i in range(nsteps):
-                            b.run(frames)
-                            if i % every != every - 1:
-                                continue
-                            b.vu_snapshot()
-                            waiting += 1
-                            if collecting:
-                                b.vu_collect_end()
-                                collecting = False
-                                waiting -= 1
-                            if waiting >= 2:
-                                b.vu_collect_begin(results, rcs)
-                                collecting = True
-                        if collecting:
-                            b.vu_collect_end()
-                            waiting -= 1
-                        while waiting:
-                            b.vu_collect(results, rcs)
-                            waiting -= 1
-                        b.sync()
-                    b.vu_reset(-1)
-                    b.sync()
-                    loop(200)
-                    t1 = time.perf_counter()
-                    loop(1000)
-                    entry[key] = round((time.perf_counter() - t1) / 1000 * 1e3, 4)
-                sweep[str(frames)] = entry
-        except Exception as e:
-            sweep["error"] = str(e)
-        out["small_blocks"] = sweep
+        out["measured_ceilings"] = measured_ceilings(b, achieved)
+        out["small_blocks"] = small_blocks(b, S, Cn, T, bps, results, rcs)
     b.close()
 
-    def kernel_only(batch, frames, warm=100, timed=100):
-        for _ in range(warm):
-            batch.run(frames)
-        batch.sync()
-        batch.timing(True)
-        batch.timing_read()
-        for _ in range(timed):
-            batch.run(frames)
-        ms, n = batch.timing_read()
-        batch.close()
-        return ms / n
-
     if rank == 0 and not args.no_extras and not eq:
-        # second line of SURVEY 8(d): VU only, 2 B/sample read -- never mixed with the above
-        v = cm.Batch(S, Cn, T, flags=cm.VU, device=local_rank)
-        if args.workload == "c2":
-            v.set_gain(-1, 2, 1000, [750, 1250])
-            v.set_chmap(-1, [1, 0])
-        else:
-            v.set_gain(-1, 1, 1000, [900])
-        v.generate(cm.GEN_NOISE, 12345, T, first_global=rank, global_step=world)
-        ms1 = kernel_only(v, T)
-        gbs = samples_per_step_rank * 2 / (ms1 * 1e-3) / 1e9
         read_ceiling = out.get("measured_ceilings", {}).get("hbm_read_ceiling_GBs", 0)
-        out["vu_only"] = {"kernel_avg_ms": round(ms1, 4), "achieved_GBs": round(gbs, 1),
-                          "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
-                          "frac_of_read_ceiling": round(gbs / read_ceiling, 4) if read_ceiling > 0 else None,
-                          "Msamples_per_s_kernel": round(samples_per_step_rank / (ms1 * 1e-3) / 1e6, 1),
-                          "algorithmic_bytes_per_sample": 2}
-        # the same read-only run with the transform as the reference creates it (gain disabled,
-        # ref: src/transform.c:107-108) and with every gain below the scale: shorter arithmetic
-        for key, g in (("vu_only_gain_disabled", None), ("vu_only_gains_below_scale", [900, 800][:Cn])):
-            v = cm.Batch(S, Cn, T, flags=cm.VU, device=local_rank)
-            if g is not None:
-                v.set_gain(-1, Cn, 1000, g)
-            if args.workload == "c2":
-                v.set_chmap(-1, [1, 0])
-            v.generate(cm.GEN_NOISE, 12345, T, first_global=rank, global_step=world)
-            ms1 = kernel_only(v, T)
-            gbs = samples_per_step_rank * 2 / (ms1 * 1e-3) / 1e9
-            out[key] = {"kernel_avg_ms": round(ms1, 4), "achieved_GBs": round(gbs, 1),
-                        "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
-
+        out.update(vu_only_lines(cm, args.workload, S, Cn, T, local_rank, rank, world, read_ceiling))
     if rank == 0 and world == 1 and not args.no_extras and args.workload == "c2":
-        # the other kernels of the path, kernel time only: never part of `value`
-        other = {}
-        try:
-            for name, (s_, c_, t_, fl, bps_, eqz) in {
-                    "c3_eq_float_planes": (8192, 1, 65536, cm.EQ | cm.OUT_F32, 6, True),
-                    "eq_stereo_int16_vu": (4096, 2, 65536, cm.EQ | cm.OUT_PCM | cm.VU, 4, True),
-                    "six_channels_pcm_vu": (2730, 6, 16384, cm.OUT_PCM | cm.VU, 4, False),
-                    "six_channels_vu_only": (2730, 6, 16384, cm.VU, 2, False)}.items():
-                o = cm.Batch(s_, c_, t_, flags=fl, device=local_rank)
-                o.set_gain(-1, 1, 1000, [900])
-                if eqz:
-                    o.set_eq(-1, cm.eq3(48000.0))
-                o.generate(cm.GEN_NOISE, 12345, t_)
-                ms1 = kernel_only(o, t_)             # ~0.1 s of warm-up: the clocks the chip then holds
-                gbs = s_ * c_ * t_ * bps_ / (ms1 * 1e-3) / 1e9
-                other[name] = {"streams": s_, "channels": c_, "frames": t_, "kernel_avg_ms": round(ms1, 4),
-                               "algorithmic_bytes_per_sample": bps_, "achieved_GBs": round(gbs, 1),
-                               "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
-        except Exception as e:
-            other["error"] = str(e)
-        out["other_kernels"] = other
+        out["other_kernels"] = other_kernels(cm, local_rank)
         try:
             out["pcie_inclusive"] = pcie_inclusive(cm, local_rank)
         except Exception as e:
@@ -717,6 +564,174 @@ def main():
         guarded_legs(printer, dist, lambda: node_vu_legs(cm, shard, dist, rank, world, local_rank, rehearsal, NB))
     sys.stdout.flush()
     printer.emit()
+
+
+def kernel_only(batch, frames, warm=100, timed=100):
+    """average kernel time (ms, HIP events) of `timed` launches after `warm` untimed ones; closes the batch"""
+    for _ in range(warm):
+        batch.run(frames)
+    batch.sync()
+    batch.timing(True)
+    batch.timing_read()
+    for _ in range(timed):
+        batch.run(frames)
+    ms, n = batch.timing_read()
+    batch.close()
+    return ms / n
+
+
+def place_off_leg(make_batch, T):
+    """what the workload's kernel takes in this process WITHOUT the placement search: a batch made the default
+    way first (the process's first two large allocations), warmed up, timed over 64 launches, freed"""
+    t_c = time.perf_counter()
+    a0 = make_batch()
+    res = {"batch_create_ms_place_off": round((time.perf_counter() - t_c) * 1e3, 1)}
+    t_w0 = time.perf_counter()
+    while time.perf_counter() - t_w0 < MIN_WARMUP_S:
+        for _ in range(16):
+            a0.run(T)
+        a0.sync()
+    res["kernel_avg_ms_place_off"] = round(kernel_only(a0, T, warm=0, timed=64), 4)
+    return res
+
+
+def traffic_from_profiles(workload, S, T):
+    """HBM bytes per launch are NOT measured in a bench run -- PMC counters need rocprofv3 passes of their own
+    (tools/hbm_pmc.sh: FETCH_SIZE and WRITE_SIZE separately, FETCH_SIZE doubled for gfx950): the figure is read
+    from the committed summary of such a run on the same workload, and labelled"""
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
+    try:
+        pmc = json.load(open(pmc_path))
+        if pmc.get("workload") == workload and pmc.get("frames") == T and pmc.get("streams") == S:
+            return pmc.get("hbm_bytes_per_launch"), (
+                "profiles/pmc_%s.json (%s; separate rocprofv3 --pmc passes, not this run)" % (
+                    workload, pmc.get("round", "round 1")))
+    except Exception:
+        pass
+    return None, None
+
+
+def measured_ceilings(b, achieved):
+    """the kernel against the ceilings measured on the same buffers as well as against the nominal
+    peak (PCM materialised: the copy with the same access shape; read-only runs: the read ceiling)"""
+    extras = {}
+    try:
+        extras["hbm_read_ceiling_GBs"] = round(b.ceiling(0, 10), 1)
+        extras["hbm_copy_ceiling_GBs"] = round(b.ceiling(1, 10), 1)
+        if extras["hbm_copy_ceiling_GBs"] > 0:
+            extras["kernel_frac_of_copy_ceiling"] = round(achieved / extras["hbm_copy_ceiling_GBs"], 4)
+    except Exception as e:           # measurement extras must not break the line
+        extras["ceiling_error"] = str(e)
+    return extras
+
+
+def small_blocks(b, S, Cn, T, bps, results, rcs):
+    """the small-block regime, same batch, fewer frames per launch.  Per block size the kernel alone,
+    the whole STEP with a VU window per block (launch + packed snapshot + host dB finish of all windows), and the
+    step when windows close every 20 blocks -- the reference's own granularity (a result every 20 reads,
+    ref: src/simple.c:370)"""
+    def loop(frames, every, nsteps):
+        # the dB finish of window k-1 runs on the helper threads beside launch and snapshot of block k+1
+        # (cmhip_batch_vu_collect_begin / _end); up to three snapshots are pending
+        collecting, waiting = False, 0
+        for i in range(nsteps):
+            b.run(frames)
+            if i % every != every - 1:
+                continue
+            b.vu_snapshot()
+            waiting += 1
+            if collecting:
+                b.vu_collect_end()
+                collecting = False
+                waiting -= 1
+            if waiting >= 2:
+                b.vu_collect_begin(results, rcs)
+                collecting = True
+        if collecting:
+            b.vu_collect_end()
+            waiting -= 1
+        while waiting:
+            b.vu_collect(results, rcs)
+            waiting -= 1
+        b.sync()
+
+    sweep = {}
+    try:
+        for frames in (512, 2880, 4096):
+            if frames >= T:
+                continue
+            b.vu_reset(-1)
+            for _ in range(3):
+                b.run(frames)
+            b.sync()
+            b.timing(True)
+            b.timing_read()
+            for _ in range(20):
+                b.run(frames)
+            ms, n = b.timing_read()
+            b.timing(False)
+            entry = {"kernel_avg_ms": round(ms / n, 4),
+                     "achieved_GBs": round(S * Cn * frames * bps / (ms / n * 1e-3) / 1e9, 1)}
+            for every, key in ((1, "step_ms_window_per_block"), (20, "step_ms_window_per_20_blocks")):
+                b.vu_reset(-1)
+                b.sync()
+                loop(frames, every, 200)
+                t1 = time.perf_counter()
+                loop(frames, every, 1000)
+                entry[key] = round((time.perf_counter() - t1) / 1000 * 1e3, 4)
+            sweep[str(frames)] = entry
+    except Exception as e:
+        sweep["error"] = str(e)
+    return sweep
+
+
+def vu_only_lines(cm, workload, S, Cn, T, device, rank, world, read_ceiling):
+    """second line of SURVEY 8(d): VU only, 2 B/sample read -- never mixed with `value`: with the workload's
+    gain, with the transform as the reference creates it (gain disabled, ref: src/transform.c:107-108), and with
+    every gain below the scale (shorter arithmetic)"""
+    samples = S * Cn * T
+    res = {}
+    for key, g in (("vu_only", [750, 1250] if workload == "c2" else [900]), ("vu_only_gain_disabled", None),
+                   ("vu_only_gains_below_scale", [900, 800][:Cn])):
+        v = cm.Batch(S, Cn, T, flags=cm.VU, device=device)
+        if g is not None:
+            v.set_gain(-1, len(g), 1000, g)
+        if workload == "c2":
+            v.set_chmap(-1, [1, 0])
+        v.generate(cm.GEN_NOISE, 12345, T, first_global=rank, global_step=world)
+        ms1 = kernel_only(v, T)
+        gbs = samples * 2 / (ms1 * 1e-3) / 1e9
+        res[key] = {"kernel_avg_ms": round(ms1, 4), "achieved_GBs": round(gbs, 1),
+                    "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    res["vu_only"].update({"frac_of_read_ceiling": round(res["vu_only"]["achieved_GBs"] / read_ceiling, 4)
+                           if read_ceiling > 0 else None,
+                           "Msamples_per_s_kernel": round(samples / (res["vu_only"]["kernel_avg_ms"] * 1e-3) / 1e6, 1),
+                           "algorithmic_bytes_per_sample": 2})
+    return res
+
+
+def other_kernels(cm, device):
+    """the other kernels of the path, kernel time only: never part of `value`"""
+    other = {}
+    try:
+        for name, (s_, c_, t_, fl, bps_, eqz) in {
+                "c3_eq_float_planes": (8192, 1, 65536, cm.EQ | cm.OUT_F32, 6, True),
+                "eq_stereo_int16_vu": (4096, 2, 65536, cm.EQ | cm.OUT_PCM | cm.VU, 4, True),
+                "six_channels_pcm_vu": (2730, 6, 16384, cm.OUT_PCM | cm.VU, 4, False),
+                "six_channels_vu_only": (2730, 6, 16384, cm.VU, 2, False)}.items():
+            o = cm.Batch(s_, c_, t_, flags=fl, device=device)
+            o.set_gain(-1, 1, 1000, [900])
+            if eqz:
+                o.set_eq(-1, cm.eq3(48000.0))
+            o.generate(cm.GEN_NOISE, 12345, t_)
+            ms1 = kernel_only(o, t_)             # ~0.1 s of warm-up: the clocks the chip then holds
+            gbs = s_ * c_ * t_ * bps_ / (ms1 * 1e-3) / 1e9
+            other[name] = {"streams": s_, "channels": c_, "frames": t_, "kernel_avg_ms": round(ms1, 4),
+                           "algorithmic_bytes_per_sample": bps_, "achieved_GBs": round(gbs, 1),
+                           "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    except Exception as e:
+        other["error"] = str(e)
+    return other
 
 
 class LinePrinter:
