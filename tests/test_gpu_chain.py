@@ -197,6 +197,32 @@ def test_product_wiring_with_tee(gpu, oracle):
         o.unref()
 
 
+def test_a_long_window_behind_a_tee_outlives_the_record_ring(gpu, oracle):
+    """700 pulls of 256 bytes without a result(): more launches than the transform's ring of 256 device windows
+    holds (the transform fetches them to the host before a slot comes round again) and more whole records than
+    the meter keeps unmerged (512: it folds them into its window on the way).  One window over all of it."""
+    cm = gpu
+    C, pulls = 1, 700
+    x = oracle.lcg(4242, pulls * 128)
+    tr, tee, enc_in, vu = _tee_chain(cm, x, C, chunk=1000, gain=(1, 1000, [1100]))
+    assert vu.mode() == 2
+    _, g = oracle.gain(C, 1, 1000, [1100])
+    want = oracle.gain_apply(g, x, C)
+    runs0 = cm.lib.cmhip_debug_run_count()
+    for i in range(pulls):
+        n, d = enc_in.read(256)
+        assert n == 256
+        assert vu.read(256) == 256
+    assert cm.lib.cmhip_debug_run_count() - runs0 == pulls and vu.mode() == 2
+    rc, r = vu.result()
+    v = oracle.vu_new(C)
+    oracle.vu_accumulate(v, want)
+    _, ro = oracle.vu_result(v)
+    assert rc == 0 and r.as_dict() == of.vu_result_dict(ro)
+    for o in (enc_in, vu, tee, tr):
+        o.unref()
+
+
 @pytest.mark.parametrize("who_leads", ["encoder", "meter", "mixed"])
 def test_meter_behind_a_tee_lags_and_cuts_blocks(gpu, oracle, who_leads):
     """The meter's reads do not line up with the transform's launches: the encoder branch pulls odd sizes
