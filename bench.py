@@ -1048,8 +1048,15 @@ def cpu_baseline(workload, channels):
                 break
     except Exception:
         pass
+    quota = None                         # a container's CPU-time quota may be far below the threads it can see
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        pass
     return {
-        "value": round(n_all / secs / 1e6, 1), "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "value": round(n_all / secs / 1e6, 1), "unit": "Msamples/s", "cores": cores, "cpu_quota_cpus": quota,
+        "kind": "port",
         "sample": "%d of the workload's streams (%d per thread) x %d frames x %d ch, same "
                   "generator and parameters, block-at-once" % (streams, per_thread, frames, channels),
         "one_thread_Msamples_s": round(n_one / secs1 / 1e6, 1),
