@@ -295,6 +295,13 @@ def main():
     if rehearsal:
         local_rank = 0
 
+    # Several ranks share the host: each sizes its dB-finish helper pool for its share of the container's
+    # CPU-time quota (the engine alone would size it for the whole quota)
+    if world > 1 and "CMHIP_POOL_THREADS" not in os.environ:
+        quota = cpu_quota()
+        if quota is not None and quota / world < 16:
+            os.environ["CMHIP_POOL_THREADS"] = str(max(1, int(quota / world) - 3))
+
     import __graft_entry__ as ge
     cm = ge.load_package()
     from libcoolmic_dsp_amd import shard
@@ -1011,6 +1018,15 @@ def pcie_inclusive(cm, device):
     return res
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max), or None when unlimited / unknown"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        return None
+
+
 def cpu_baseline(workload, channels):
     """The CPU oracle (kind "port": scalar restatement of src/transform.c:101-124 and
     src/vumeter.c:161-218) on this host, on a bounded sample of the same workload."""
@@ -1048,12 +1064,7 @@ def cpu_baseline(workload, channels):
                 break
     except Exception:
         pass
-    quota = None                         # a container's CPU-time quota may be far below the threads it can see
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        quota = None if q == "max" else round(int(q) / int(per), 2)
-    except Exception:
-        pass
+    quota = cpu_quota()                  # a container's CPU-time quota may be far below the threads it can see
     return {
         "value": round(n_all / secs / 1e6, 1), "unit": "Msamples/s", "cores": cores, "cpu_quota_cpus": quota,
         "kind": "port",
