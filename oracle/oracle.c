@@ -7,9 +7,14 @@
  * integer mean then 20*log10(sqrt(p)/32768) clamped to <= 0 in double.
  * Build with -ffp-contract=off (oracle/Makefile does).
  *
- * Pinning: integer gain / framing / VU are pinned to SURVEY.md 8(c) vectors
- * (tests/test_oracle_golden.py).  Channel map, float converts and the biquad
- * EQ are PARITY UNPINNED: the reference has no such code, this file is the spec.
+ * PARITY UNPINNED.  The reference ships no tests, fixtures or golden vectors, and
+ * it cannot be built in this image (its transform.c / vumeter.c / iohandle.c need libigloo's
+ * headers; a build against written stand-ins is not a build of the reference), so there is no
+ * oracle/_ref.  What this file IS checked against, bit for bit: the vectors of SURVEY.md 8(c)
+ * (tests/golden/survey_8c.json, tests/test_oracle_golden.py) -- outputs the survey stage captured
+ * from such a stand-in build, good evidence but not a pin -- and a second restatement in pure
+ * Python written from the reference's text (tests/test_second_witness.py).  Channel map, float
+ * converts and the biquad EQ have no counterpart in the reference at all: this file is their spec.
  */
 #define _GNU_SOURCE
 #include "oracle.h"
