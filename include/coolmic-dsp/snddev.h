@@ -1,9 +1,11 @@
 /*
- * snddev.h -- PCM sources used to drive the chain: "null" (silence) and "sine"
- * (1 kHz, amplitude 32766, mono).  Same constructor and handle contract as the
- * reference (ref: include/coolmic-dsp/snddev.h:40-83, src/snddev.c:98-169,
- * src/snddev_sine.c:118-193, src/snddev_null.c:33-55).  Only the capture (RX)
- * side is provided; hardware drivers are out of scope.
+ * snddev.h -- PCM sources used to drive the chain: "null" (silence), "sine" (1 kHz,
+ * amplitude 32766, mono) and "stdio" (a raw PCM file).  Same functions and contracts as
+ * the reference (ref: include/coolmic-dsp/snddev.h:40-83, src/snddev.c:98-215,
+ * src/snddev_sine.c:118-193, src/snddev_null.c:33-55, src/snddev_stdio.c:50-78), both the
+ * capture handle and the playback side.  Hardware drivers (oss, opensl) and the driver
+ * vtable they plug into are the reference's own: inside its build its snddev*.c stay
+ * (INTEGRATION.md 3), and this header is the stand-alone library's.
  */
 #ifndef __COOLMIC_DSP_SNDDEV_H__
 #define __COOLMIC_DSP_SNDDEV_H__
@@ -30,12 +32,20 @@ typedef struct coolmic_snddev coolmic_snddev_t;
 
 /* NULL for rate/channels/flags of 0, an unknown driver, or a driver that refuses
  * the format (sine: mono only, rate must be 8/16/24/32/44/44.1/48/96 kHz; stdio: the file
- * must open for reading, capture only) */
+ * must open -- "rb" for RX, "wb" for TX, "w+b" for both) */
 coolmic_snddev_t   *coolmic_snddev_new(const char *name, igloo_ro_t associated, const char *driver,
                                        void *device, uint_least32_t rate, unsigned int channels,
                                        int flags, ssize_t buffer);
+/* the handle whose PCM is to be played back by coolmic_snddev_iter(); NULL detaches
+ * (ref: src/snddev.c:143-152) */
+int                 coolmic_snddev_attach_iohandle(coolmic_snddev_t *self, coolmic_iohandle_t *handle);
 /* endless capture handle (no eof callback), keeps the device alive while it lives */
 coolmic_iohandle_t *coolmic_snddev_get_iohandle(coolmic_snddev_t *self);
+/* one round of playback: flushes what the device has not taken yet, then reads up to 1 KiB from
+ * the attached handle and hands it to the device.  COOLMIC_ERROR_NONE, _BUSY (the device took
+ * only part), _GENERIC (read or write failed).  null and sine discard, stdio writes to its file
+ * (ref: src/snddev.c:171-215) */
+int                 coolmic_snddev_iter(coolmic_snddev_t *self);
 
 #ifdef __cplusplus
 }

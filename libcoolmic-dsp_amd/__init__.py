@@ -181,6 +181,8 @@ SIGNATURES = {
     "coolmic_snddev_new": (_vp, [C.c_char_p, _vp, C.c_char_p, _vp, C.c_uint32, C.c_uint, C.c_int,
                                  ssize_t]),
     "coolmic_snddev_get_iohandle": (_vp, [_vp]),
+    "coolmic_snddev_attach_iohandle": (C.c_int, [_vp, _vp]),
+    "coolmic_snddev_iter": (C.c_int, [_vp]),
     # include/coolmic-dsp/tee.h
     "coolmic_tee_new": (_vp, [C.c_char_p, _vp, C.c_size_t]),
     "coolmic_tee_attach_iohandle": (C.c_int, [_vp, _vp]),
@@ -663,14 +665,21 @@ class IoHandle:
 
 
 class Snddev:
-    def __init__(self, driver, rate=48000, channels=1, flags=1):
-        self.ptr = lib.coolmic_snddev_new(None, None, driver.encode() if driver else None, None,
+    def __init__(self, driver, rate=48000, channels=1, flags=1, device=None):
+        self.ptr = lib.coolmic_snddev_new(None, None, driver.encode() if driver else None,
+                                          C.c_char_p(device.encode()) if device else None,
                                           rate, channels, flags, -1)
         if not self.ptr:
             raise CoolmicError("coolmic_snddev_new", ERROR_GENERIC)
 
     def get_iohandle(self):
         return IoHandle(lib.coolmic_snddev_get_iohandle(self.ptr))
+
+    def attach(self, handle):
+        return lib.coolmic_snddev_attach_iohandle(self.ptr, handle.ptr if handle else None)
+
+    def iter(self):
+        return lib.coolmic_snddev_iter(self.ptr)
 
     def unref(self):
         if self.ptr:

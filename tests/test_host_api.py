@@ -320,7 +320,6 @@ def test_stdio_source_replays_a_raw_pcm_file(cm, tmp_path):
     new = cm.lib.coolmic_snddev_new
     assert not new(None, None, b"stdio", None, 48000, 2, 1, -1)                       # no file name
     assert not new(None, None, b"stdio", str(tmp_path / "missing").encode(), 48000, 2, 1, -1)
-    assert not new(None, None, b"stdio", str(f).encode(), 48000, 2, 2, -1)            # playback: out of scope
     name = str(f).encode()
     d = new(None, None, b"stdio", name, 48000, 2, 1, -1)
     assert d
@@ -331,6 +330,43 @@ def test_stdio_source_replays_a_raw_pcm_file(cm, tmp_path):
     assert h.read(10) == (0, b"")
     h.unref()
     assert cm.lib.coolmic_feature_check(b"driver:stdio") == 1
+
+
+def test_snddev_playback_side(cm, tmp_path):
+    """coolmic_snddev_attach_iohandle + coolmic_snddev_iter (ref: src/snddev.c:143-152, 171-215): one round
+    flushes what the device has not taken, then moves up to 1 KiB from the attached handle to the device;
+    "stdio" opened for TX writes its file, "null" and "sine" discard (ref: src/snddev_null.c, snddev_sine.c)."""
+    data = bytes((i * 7 + 3) & 0xff for i in range(5000))
+    out = tmp_path / "playback.pcm"
+    dev = cm.Snddev("stdio", 48000, 2, flags=2, device=str(out))                     # TX: "wb"
+    assert cm.lib.coolmic_snddev_iter(None) == cm.ERROR_FAULT
+    assert dev.iter() == cm.ERROR_GENERIC                                            # nothing attached: the read fails
+    src = cm.IoHandle.from_bytes(data, chunk=700)
+    assert dev.attach(src) == 0 and src.refcount() == 2
+    src.unref()
+    for _ in range(5):                                                               # 5 x 1 KiB >= 5000 bytes
+        assert dev.iter() == cm.ERROR_NONE
+    assert dev.iter() == cm.ERROR_NONE                                               # source exhausted: nothing to do
+    assert dev.attach(None) == 0
+    h = dev.get_iohandle()
+    assert h.read(16) == (0, b"")                                                    # a file opened for writing reads nothing
+    h.unref()
+    dev.unref()                                                                      # closes the file
+    assert out.read_bytes() == data
+    for driver in ("null", "sine"):
+        d = cm.Snddev(driver, 48000, 1, flags=3)
+        s2 = cm.IoHandle.from_bytes(data[:1500])
+        assert d.attach(s2) == 0
+        s2.unref()
+        assert d.iter() == cm.ERROR_NONE and d.iter() == cm.ERROR_NONE and d.iter() == cm.ERROR_NONE
+        d.unref()
+    # both directions on one file (ref: "w+b")
+    both = cm.Snddev("stdio", 48000, 1, flags=3, device=str(tmp_path / "both.pcm"))
+    s3 = cm.IoHandle.from_bytes(b"abcdefgh")
+    assert both.attach(s3) == 0 and both.iter() == cm.ERROR_NONE
+    s3.unref()
+    both.unref()
+    assert (tmp_path / "both.pcm").read_bytes() == b"abcdefgh"
 
 
 def test_vu_colour_helpers_match_the_restatement(cm, oracle):
