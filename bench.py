@@ -773,8 +773,10 @@ def guarded_legs(printer, dist, legs):
     dist.barrier()                             # (rank 0 has been busy with the extras of its line until here)
 
     def fire():
-        out.setdefault("node_vu", {})
-        if "error" not in out["node_vu"]:
+        nv = out.get("node_vu")
+        if nv and "rccl_ranks" in nv:          # this rank's legs were through: a peer never reached the closing barrier
+            nv.setdefault("note", "a rank did not reach the closing barrier within %.0f s" % limit)
+        elif not nv or "error" not in nv:
             out["node_vu"] = {"error": "the config-4 / config-5 legs did not finish within %.0f s on rank %d "
                                        "(a rank failed or a collective never completed); value and roofline above "
                                        "are unaffected" % (limit, printer.rank)}
