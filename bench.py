@@ -545,6 +545,11 @@ def main():
         except Exception:
             pass
 
+    # the parity gate that goes with every benchmark -- one more block of the same batch, outside the
+    # timed region, sampled streams against the oracle (which is here as the checker, as in cpu_baseline)
+    if rank == 0 and not args.no_cpu:
+        out["parity_gate"] = parity_gate(cm, b, args.workload, S, Cn, T, first_global, global_step)
+
     if rank == 0 and not args.no_extras and not eq:
         out["measured_ceilings"] = measured_ceilings(b, achieved)
         out["small_blocks"] = small_blocks(b, S, Cn, T, bps, results, rcs)
@@ -571,6 +576,8 @@ def main():
         guarded_legs(printer, dist, lambda: node_vu_legs(cm, shard, dist, rank, world, local_rank, rehearsal, NB))
     sys.stdout.flush()
     printer.emit()
+    if out.get("parity_gate", {}).get("ok") is False:
+        sys.exit("bench.py: the parity gate failed -- the numbers above are not results of the reference's arithmetic")
 
 
 def kernel_only(batch, frames, warm=100, timed=100):
@@ -616,6 +623,60 @@ def traffic_from_profiles(workload, S, T):
     except Exception:
         pass
     return None, None
+
+
+def parity_gate(cm, b, workload, S, Cn, T, first_global, global_step):
+    """One block of the benchmarked batch against the CPU oracle, bit for bit, on a sample of its streams: the
+    int16 PCM and the VU window of that block (configs 2, 4, 5: integer gain, channel map, first-max peak, sum of
+    squares, dB doubles), or the float planes of the equaliser from cleared filter state (config 3).  The oracle
+    is test infrastructure; it checks here, it is never the thing measured."""
+    import numpy as np
+    from oracle import oracle_ffi
+    orc = oracle_ffi.Oracle()
+    pick = sorted({0, 1, S // 2, S - 1})
+    gate = {"streams_checked": pick, "frames": T, "against": "oracle/ (scalar C restatement of the reference's loops)"}
+    try:
+        if workload == "c3":
+            b.eq_reset(-1)
+            b.run(T)
+            b.sync()
+            coef = cm.eq3(48000.0)
+            q = (oracle_ffi.Biquad * 3)()
+            for i in range(3):
+                q[i].b0, q[i].b1, q[i].b2, q[i].a1, q[i].a2 = [float(v) for v in coef[5 * i:5 * i + 5]]
+            _, g = orc.gain(1, 1, 1000, [900])
+            if os.environ.get("COOLMIC_BENCH_GAIN", "1") == "0":
+                g = None
+            ok = True
+            for s_ in pick:
+                wf, _ = orc.eq_run_mono(g, q, 3, np.zeros(12, dtype=np.float32),
+                                        orc.lcg(12345 + first_global + s_ * global_step, T))
+                ok = ok and np.array_equal(b.download_f32(s_, 0, T).view(np.uint32), wf.view(np.uint32))
+            gate["float_planes_bit_equal"] = bool(ok)
+            gate["ok"] = bool(ok)
+            return gate
+        b.vu_reset(-1)
+        b.run(T)
+        res, rcs = b.vu_results()
+        gains = [750, 1250] if workload == "c2" else [900]
+        _, g = orc.gain(Cn, len(gains), 1000, gains)
+        if workload != "c2" and os.environ.get("COOLMIC_BENCH_GAIN", "1") == "0":
+            g = oracle_ffi.Gain()                # (the bench ran with the gain disabled)
+        pcm_ok = vu_ok = True
+        for s_ in pick:
+            x = orc.lcg(12345 + first_global + s_ * global_step, T * Cn)
+            if workload == "c2":
+                x = orc.chmap([1, 0], x, Cn)
+            want = orc.gain_apply(g, x, Cn)
+            pcm_ok = pcm_ok and np.array_equal(b.download(s_, T), want)
+            v = orc.vu_new(Cn)
+            orc.vu_accumulate(v, want)
+            _, r = orc.vu_result(v)
+            vu_ok = vu_ok and rcs[s_] == 0 and res[s_].as_dict() == oracle_ffi.vu_result_dict(r)
+        gate.update({"pcm_byte_equal": bool(pcm_ok), "vu_results_bit_equal": bool(vu_ok), "ok": bool(pcm_ok and vu_ok)})
+    except Exception as e:
+        gate.update({"ok": False, "error": "%s: %s" % (type(e).__name__, e)})
+    return gate
 
 
 def measured_ceilings(b, achieved):
