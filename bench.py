@@ -452,9 +452,9 @@ def main():
 
     # Kernel time: the kernel's own dispatch stamps HIP events on its stream.  The events cost a launch about
     # 5 us of its stream's time (tools/step_overhead.py: 0.3334 -> 0.3380 ms per step of config 2), so every
-    # eighth launch of the timed region carries them, every fourth of a short region (the driver's --steps 20), every
-    # one of a very short one.
-    time_every = 8 if args.steps >= 64 else (4 if args.steps >= 16 else 1)
+    # eighth launch of the timed region carries them -- every one when the region is short (the driver's --steps 20:
+    # SURVEY 8(d) wants the kernel time over at least 20 timed launches).
+    time_every = 8 if args.steps >= 64 else 1
     b.timing(time_every)
     b.timing_read()
     barrier()
