@@ -344,8 +344,20 @@ __device__ __forceinline__ void run_fast(const RunArgs &a)
     }
 }
 
+// Waves per SIMD.  The form that writes PCM and keeps a window (NW waves per workgroup: configs 2, 4, 5) is held to
+// FOUR waves per SIMD: on the same 16 array pairs (PF_SNAP=1 tools/placement_forms.py, round 3) 0.3294 ms against
+// 0.3447 ms at the seven waves its 72 registers would allow -- 5 waves 0.3364, 6 0.3489, 3 0.3438, 2 0.427, and 8
+// (64 registers, spills) 0.363.  Fewer waves in flight keep the chip-wide access window compact, as the short tiles
+// do; with sixteen waves a CU still has 64 KiB of loads under way.  $CMHIP_FAST_WPE at build time overrides (A/B).
+#ifndef CMHIP_FAST_WPE
+#define CMHIP_FAST_WPE 4
+#endif
+// (The other families were swept the same way and gain nothing: the one-wave PCM-only form is within noise for 3-8
+// waves, k_run_wide at its best as it is, and k_run_rows / the read-only entry already run at the 3-4 waves their
+// registers leave -- forcing more makes them spill: profiles/r03_occupancy_forms.txt.)
 template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U, int NW = 1>
-__global__ __launch_bounds__(64 * NW) void k_run_fast(RunArgs a)
+__global__ __launch_bounds__(64 * NW)
+__attribute__((amdgpu_waves_per_eu(NW > 1 ? CMHIP_FAST_WPE : 1, NW > 1 ? CMHIP_FAST_WPE : 8))) void k_run_fast(RunArgs a)
 {
     run_fast<C, WRITE_PCM, WRITE_F32, DO_VU, U, NW>(a);
     done_epilogue(a.done_flag, a.done_seq);

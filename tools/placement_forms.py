@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """{window merged by workgroups of 1, 4, 8, 16 waves; no window} x {input and output arrays of the same placement class, of different
 ones}: the config-2 kernel in one process, on the slowest and the fastest of N x N array pairs.
-PF_SNAP=1: a VU window per launch (snapshot + collect every step, as bench.py runs)."""
+PF_SNAP=1: a VU window per launch (snapshot + collect every step, as bench.py runs); PF_NOVU=1: the other builds
+named on the command line run without a window (PCM only)."""
 import ctypes as C
 import importlib
 import os
@@ -54,7 +55,7 @@ for extra in sys.argv[3:]:                # other builds of the library (timing-
     cm2 = importlib.util.module_from_spec(spec)
     sys.modules[tag] = cm2
     spec.loader.exec_module(cm2)
-    b2 = cm2.Batch(S, Cn, T, flags=(cm2.VU if RO else cm2.OUT_PCM | cm2.VU) | cm2.EXTSLOTS)
+    b2 = cm2.Batch(S, Cn, T, flags=(cm2.VU if RO else (cm2.OUT_PCM if os.environ.get("PF_NOVU") else cm2.OUT_PCM | cm2.VU)) | cm2.EXTSLOTS)
     if Cn == 2:
         b2.set_gain(-1, 2, 1000, [750, 1250])
         b2.set_chmap(-1, [1, 0])
