@@ -984,7 +984,9 @@ hipError_t launch_run(const RunArgs &a, const RunTune &tune, hipStream_t st, hip
         // 0.333 ms, against 0.345-0.354 for eight waves and 0.340-0.351 for one).  The read-only runs
         // (16 KiB tiles, a quarter of the atomics per byte) lose with more than one wave: 0.171 / 0.175 /
         // 0.181 / 0.207 ms for 1 / 2 / 4 / 8.
-        const u32 nw = tune.fast_nw ? tune.fast_nw : FAST_NW;
+        // (streams of fewer than three tiles -- blocks of a few hundred frames -- take the one-wave form: a
+        // workgroup of four waves would leave most of its waves idle there, and it is held to four per SIMD)
+        const u32 nw = tune.fast_nw ? tune.fast_nw : (b.chunks >= 3u ? FAST_NW : 1u);
         const u32 gridw = a.streams * ((b.chunks + nw - 1u) / nw);
         if ((u64)a.streams * ((b.chunks + nw - 1u) / nw) >= (1ull << 31))
             return hipErrorInvalidValue;
