@@ -397,11 +397,13 @@ def test_many_channel_read_only_runs_without_gain(gpu, oracle, C):
 
 
 def test_peak_tie_breaks_across_lanes_waves_chunks_and_launches(gpu, oracle):
-    """first max-|x| in interleaved order wins, also when the candidates sit in
-    different lanes, waves, wave-chunks or launches (ref: src/vumeter.c:163-168)"""
+    """first max-|x| in interleaved order wins, also when the candidates sit in different lanes, rows of a
+    step, steps, tiles or launches (ref: src/vumeter.c:163-168); read-only and writing PCM in place (the
+    row kernel looks the winning step up again in what it wrote)"""
     cm = gpu
-    T = 70000                      # several wave-chunks per stream
-    for C in (1, 2, 3):
+    T = 70000                      # several tiles per stream
+    for C, flags in ((1, cm.VU), (2, cm.VU), (3, cm.VU), (3, cm.OUT_PCM | cm.VU | cm.INPLACE), (6, cm.VU),
+                     (6, cm.OUT_PCM | cm.VU), (12, cm.VU), (12, cm.OUT_PCM | cm.VU | cm.INPLACE)):
         spots = [(5, 3000), (9, -3000), (1023, 3000), (1024, -3000), (8 * 64 * 4 + 1, 3000),
                  (40000, -3000), (69999, 3000)]
         cases = []
@@ -416,15 +418,20 @@ def test_peak_tie_breaks_across_lanes_waves_chunks_and_launches(gpu, oracle):
         if C > 1:
             x[50 * C + 1] = 777
         cases.append(x)
+        # the same magnitude in every sample from some frame on, signs alternating: every lane, row and tile ties
+        x = np.zeros(T * C, dtype=np.int16)
+        x[(31 * C + 1):] = 4321
+        x[(31 * C + 1)::2] = -4321
+        cases.append(x)
         S = len(cases)
-        b = cm.Batch(S, C, T, flags=cm.VU)
+        b = cm.Batch(S, C, T, flags=flags)
         for s in range(S):
             b.upload(s, cases[s])
         b.run(T)
         for s in range(S):
             rc, r = b.vu_result(s)
             _, ro = _oracle_vu(oracle, [cases[s]], C)
-            assert rc == 0 and r.as_dict() == of.vu_result_dict(ro), (C, s)
+            assert rc == 0 and r.as_dict() == of.vu_result_dict(ro), (C, flags, s)
         # same value in two launches of one window: the first launch keeps the peak
         blk1 = np.zeros(T * C, dtype=np.int16)
         blk2 = np.zeros(T * C, dtype=np.int16)
