@@ -212,6 +212,8 @@ for _name, (_res, _args) in SIGNATURES.items():
 # not in a public header: host-logic test hooks
 lib.cmhip_test_magic.restype = None
 lib.cmhip_test_magic.argtypes = [C.c_uint16, _P(C.c_uint32), _P(C.c_uint32)]
+lib.cmhip_test_merge_windows.restype = C.c_int
+lib.cmhip_test_merge_windows.argtypes = [_P(C.c_uint64), C.c_uint, C.c_uint, C.c_uint, _P(VuResult)]
 lib.cmhip_debug_run_count.restype = C.c_ulonglong
 lib.cmhip_debug_run_count.argtypes = []
 lib.coolmic_debug_vumeter_mode.restype = C.c_int
@@ -255,6 +257,16 @@ def magic(scale):
     m, s = C.c_uint32(), C.c_uint32()
     lib.cmhip_test_magic(scale, C.byref(m), C.byref(s))
     return m.value, s.value
+
+
+def merge_windows(windows, channels, rate=48000):
+    """Test hook: raw VU windows (rows of 33 uint64: 16 sums of squares, 16 peak keys, samples accounted), one
+    per launch in stream order, merged on the host as a meter behind a tee merges them, and finished."""
+    import numpy as np
+    w = np.ascontiguousarray(windows, dtype=np.uint64).reshape(-1, 33)
+    r = VuResult()
+    rc = lib.cmhip_test_merge_windows(w.ctypes.data_as(_P(C.c_uint64)), w.shape[0], channels, rate, C.byref(r))
+    return rc, r
 
 
 def sine_period(rate):

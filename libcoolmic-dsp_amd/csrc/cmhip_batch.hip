@@ -1791,6 +1791,24 @@ extern "C" CMHIP_INTERNAL int cmhip_vu_raw_finish(const cmhip_vu_raw_t *w, unsig
     return COOLMIC_ERROR_NONE;
 }
 
+// test hook (host logic, needs no GPU): `count` raw windows of 33 words each (16 sums, 16 keys, samples), one after
+// the other in stream order, merged as a meter behind a tee merges the records of the launches it has consumed
+// (csrc/vumeter.c), and finished
+extern "C" int cmhip_test_merge_windows(const uint64_t *windows, unsigned int count, unsigned int channels,
+                                        unsigned int rate, coolmic_vumeter_result_t *out)
+{
+    if (!windows || !out)
+        return COOLMIC_ERROR_FAULT;
+    cmhip_vu_raw_t acc;
+    memset(&acc, 0, sizeof(acc));
+    for (unsigned int i = 0; i < count; i++) {
+        cmhip_vu_raw_t w;
+        memcpy(&w, windows + (size_t)i * 33u, sizeof(w));
+        cmhip_vu_raw_merge(&acc, &w, channels);
+    }
+    return cmhip_vu_raw_finish(&acc, channels, rate, out);
+}
+
 // ---------------------------------------------------------------------------
 // node-global VU
 

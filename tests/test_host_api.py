@@ -402,3 +402,56 @@ def test_vu_colour_helpers_match_the_restatement(cm, oracle):
         assert pw[i] == o.oracle_ahsv2argb(1.0, o.oracle_power2hue(res[i].global_power), 1.0, 1.0)
         assert pk[i] == o.oracle_ahsv2argb(1.0, o.oracle_peak2hue(res[i].global_peak), 1.0, 1.0)
     assert pk[2] == 0xFFFF0000
+
+
+def _raw_window(x, C):
+    """one launch's raw VU window of the interleaved block x, as the device keeps it (cmhip_internal.h:
+    key = |peak| << 47 | (~index & (2^46 - 1)) << 1 | negative, index in interleaved samples of the block)"""
+    w = np.zeros(33, dtype=np.uint64)
+    v = x.astype(np.int64)
+    for c in range(C):
+        col = v[c::C]
+        w[c] = np.uint64(int((col * col).sum()))
+        mag = np.abs(col)
+        if mag.size and mag.max() > 0:
+            f = int(np.argmax(mag))                      # the first of the largest
+            idx = f * C + c
+            w[16 + c] = np.uint64((int(mag[f]) << 47) | ((~idx & ((1 << 46) - 1)) << 1) | (1 if col[f] < 0 else 0))
+    w[32] = np.uint64(x.size)
+    return w
+
+
+@pytest.mark.parametrize("C", [1, 2, 6])
+def test_window_records_merge_like_one_window(cm, oracle, C):
+    """The host arithmetic a meter behind a tee relies on (csrc/vumeter.c, cmhip_vu_raw_merge / _finish): the
+    windows of consecutive launches, merged in stream order, give the reference's result over the whole stretch
+    (ref: src/vumeter.c:161-177, 189-218) -- sums add, an equal peak in a later launch does not replace an
+    earlier one, the global peak is the earliest of the largest across channels.  No GPU involved."""
+    from oracle import oracle_ffi as of
+    rng = np.random.default_rng(77 + C)
+    for trial in range(40):
+        nblk = int(rng.integers(1, 9))
+        kind = trial % 4
+        blocks = []
+        for _ in range(nblk):
+            n = int(rng.integers(0, 700)) * C
+            if kind == 0:
+                x = rng.integers(-32768, 32768, size=n, dtype=np.int64).astype(np.int16)
+            elif kind == 1:                              # ties everywhere, both signs
+                x = rng.choice(np.array([-32768, -32767, 0, 32767], dtype=np.int16), size=n)
+            elif kind == 2:                              # small values: ties across launches and channels
+                x = rng.integers(-3, 4, size=n, dtype=np.int64).astype(np.int16)
+            else:
+                x = np.zeros(n, dtype=np.int16)          # silence (maybe with one sample somewhere)
+                if n and rng.random() < 0.5:
+                    x[int(rng.integers(0, n))] = int(rng.choice([-5, 5]))
+            blocks.append(x)
+        v = oracle.vu_new(C)
+        for x in blocks:
+            if x.size:
+                oracle.vu_accumulate(v, x)
+        rc_o, r_o = oracle.vu_result(v)
+        rc, r = cm.merge_windows(np.stack([_raw_window(x, C) for x in blocks]), C)
+        assert rc == rc_o, (C, trial)
+        if rc_o == 0:
+            assert r.as_dict() == of.vu_result_dict(r_o), (C, trial)
