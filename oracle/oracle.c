@@ -7,10 +7,13 @@
  * integer mean then 20*log10(sqrt(p)/32768) clamped to <= 0 in double.
  * Build with -ffp-contract=off (oracle/Makefile does).
  *
- * PARITY UNPINNED.  The reference ships no tests, fixtures or golden vectors, and
- * it cannot be built in this image (its transform.c / vumeter.c / iohandle.c need libigloo's
+ * PARITY UNPINNED for the hot path.  The reference ships no tests, fixtures or golden vectors, and
+ * the path's files cannot be built in this image (its transform.c / vumeter.c / iohandle.c need libigloo's
  * headers; a build against written stand-ins is not a build of the reference), so there is no
- * oracle/_ref.  What this file IS checked against, bit for bit: the vectors of SURVEY.md 8(c)
+ * oracle/_ref for them.  (The one exception is at the path's edge: src/util.c, the VU colour helpers, compiles
+ * from its own source -- oracle/_ref/libref_util.so -- and the three functions at the end of this file are held
+ * bit for bit against that build and the vectors taken from it: tests/test_ref_util.py.)  What the rest IS
+ * checked against, bit for bit: the vectors of SURVEY.md 8(c)
  * (tests/golden/survey_8c.json, tests/test_oracle_golden.py) -- outputs the survey stage captured
  * from such a stand-in build, good evidence but not a pin -- and a second restatement in pure
  * Python written from the reference's text (tests/test_second_witness.py).  Channel map, float

@@ -164,8 +164,9 @@ void oracle_eq_run_mono(const oracle_gain_t *g, const oracle_biquad_t *q, unsign
                         float *state, const int16_t *in, float *out_f32, int16_t *out_i16,
                         size_t n);
 
-/* ---- VU presentation helpers (ref: src/util.c:30-138); PARITY UNPINNED: the reference holds
- * no vectors for them, this restatement follows the source text ------------------------- */
+/* ---- VU presentation helpers (ref: src/util.c:30-138).  PINNED: the reference's util.c compiles from its
+ * own source (oracle/Makefile, target _ref) and these are bit-equal to that build over every peak value and
+ * dense grids of powers and colours (tests/test_ref_util.py, tests/golden/ref_util.json) ------------------ */
 uint32_t oracle_ahsv2argb(double alpha, double hue, double saturation, double value);
 double oracle_power2hue(double power);      /* "default" profile */
 double oracle_peak2hue(int16_t peak);       /* "default" profile */

@@ -115,6 +115,22 @@ def load():
     return lib
 
 
+def load_ref_util():
+    """oracle/_ref/libref_util.so -- the reference's own src/util.c compiled by `make -C oracle _ref`
+    (only where the reference's sources are present; the built file travels to the GPU box).  None when absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_util.so")
+    if not os.path.exists(path):
+        return None
+    ref = C.CDLL(path)
+    ref.coolmic_util_ahsv2argb.restype = C.c_uint32
+    ref.coolmic_util_ahsv2argb.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double]
+    ref.coolmic_util_power2hue.restype = C.c_double
+    ref.coolmic_util_power2hue.argtypes = [C.c_double, C.c_char_p]
+    ref.coolmic_util_peak2hue.restype = C.c_double
+    ref.coolmic_util_peak2hue.argtypes = [C.c_int16, C.c_char_p]
+    return ref
+
+
 # ---------------------------------------------------------------------------
 # numpy-level helpers used by the parity tests
 

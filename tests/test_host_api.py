@@ -370,8 +370,8 @@ def test_snddev_playback_side(cm, tmp_path):
 
 
 def test_vu_colour_helpers_match_the_restatement(cm, oracle):
-    """SURVEY 8f-4 (ref: src/util.c).  Parity unpinned: no reference vectors exist; product and
-    oracle restatement are compared over a grid, plus the values the source text fixes."""
+    """SURVEY 8f-4 (ref: src/util.c).  Product and oracle restatement compared over a grid, plus the values the
+    source text fixes; tests/test_ref_util.py holds both against a build of the reference's own util.c."""
     import math
     lib, o = cm.lib, oracle.lib
     for p in [-200.0, -20.0001, -20.0, -19.9, -10.0, -3.0111266389980154, -1e-9, 0.0, 0.5, -math.inf]:
