@@ -40,10 +40,13 @@ const char *coolmic_features(void)
     return "features " COOLMIC_HOST_FEATURES " " COOLMIC_FEATURE_ACCEL_HIP;
 }
 
-/* whole-word match inside the space separated list */
+/* 1 when the list holds `feature` at the start of a word and a blank or the end behind it.  The text is compared as
+ * it stands, so a query of several words matches where those words follow each other, and after a match that is not
+ * followed by a blank the search goes on behind the matched text -- both as the reference does it
+ * (ref: src/coolmic-dsp.c:85-112; held against a build of that file in tests/test_ref_core.py). */
 int coolmic_feature_check(const char *feature)
 {
-    const char *list = coolmic_features();
+    const char *at = coolmic_features();
     size_t want;
 
     if (feature == NULL)
@@ -51,14 +54,15 @@ int coolmic_feature_check(const char *feature)
     if (*feature == 0)
         return COOLMIC_ERROR_INVAL;
     want = strlen(feature);
-    while (*list) {
-        const char *end = strchr(list, ' ');
-        size_t len = end ? (size_t)(end - list) : strlen(list);
-        if (len == want && memcmp(list, feature, want) == 0)
-            return 1;
-        if (end == NULL)
-            break;
-        list = end + 1;
+    for (;;) {
+        if (strncmp(at, feature, want) == 0) {
+            if (at[want] == 0 || at[want] == ' ')
+                return 1;
+            at += want;
+        }
+        at = strchr(at, ' ');
+        if (at == NULL)
+            return 0;
+        at++;
     }
-    return 0;
 }

@@ -33,6 +33,12 @@ int coolmic_logging_log_real(const char *file, unsigned long int line, const cha
         return COOLMIC_ERROR_FAULT;
     if (cb == NULL)                          /* the hot path logs at DEBUG on every read */
         return COOLMIC_ERROR_NONE;
+    /* a source path is shown from its "coolmic/" directory on (ref: src/logging.c:66-68) */
+    if (file != NULL) {
+        const char *cut = strstr(file, "/coolmic/");
+        if (cut != NULL)
+            file = cut + 1;
+    }
 
     va_start(ap, format);
     n = vasprintf(&user, format, ap);

@@ -131,6 +131,48 @@ def load_ref_util():
     return ref
 
 
+LOG_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.c_char_p)
+
+
+def bind_core(lib):
+    """prototypes of <coolmic-dsp/coolmic-dsp.h> / <coolmic-dsp/logging.h> on a library that defines them"""
+    lib.coolmic_error2string.restype = C.c_char_p
+    lib.coolmic_error2string.argtypes = [C.c_int]
+    lib.coolmic_features.restype = C.c_char_p
+    lib.coolmic_features.argtypes = []
+    lib.coolmic_feature_check.restype = C.c_int
+    lib.coolmic_feature_check.argtypes = [C.c_char_p]
+    lib.coolmic_logging_level2string.restype = C.c_char_p
+    lib.coolmic_logging_level2string.argtypes = [C.c_int]
+    lib.coolmic_logging_set_cb_simple.restype = C.c_int
+    lib.coolmic_logging_set_cb_simple.argtypes = [LOG_CB]
+    lib.coolmic_logging_log_real.restype = C.c_int       # (variadic: arguments are converted per call)
+    return lib
+
+
+def load_ref_core():
+    """oracle/_ref/libref_core.so -- the reference's own src/coolmic-dsp.c + src/logging.c compiled by
+    `make -C oracle _ref` (with HAVE_ENC_OPUS and HAVE_SNDDRV_DRIVER_STDIO).  None when absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_core.so")
+    if not os.path.exists(path):
+        return None
+    return bind_core(C.CDLL(path))
+
+
+def log_message(lib, file, line, component, level, error, text):
+    """what `lib` hands its log callback for one coolmic_logging_log_real("%s", text) call: (rc, [(level, msg)])"""
+    seen = []
+    cb = LOG_CB(lambda lvl, msg: seen.append((lvl, msg)) or 0)
+    lib.coolmic_logging_set_cb_simple(cb)
+    try:
+        rc = lib.coolmic_logging_log_real(C.c_char_p(file), C.c_ulong(line), C.c_char_p(component), C.c_int(level),
+                                          C.c_int(error), C.c_char_p(b"%s" if text is not None else None),
+                                          C.c_char_p(text))
+    finally:
+        lib.coolmic_logging_set_cb_simple(LOG_CB())
+    return rc, seen
+
+
 # ---------------------------------------------------------------------------
 # numpy-level helpers used by the parity tests
 
