@@ -281,6 +281,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
+    # several processes on the GPUs of one host: the driver here supports dmabuf IPC only, and RCCL's
+    # hipIpcGetMemHandle fails without this (set before anything initialises HIP; a value already there stays)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     # torch is plumbing for the multi-rank run only: rendezvous, the barrier and the clock over
     # the ranks, all over gloo on the CPU -- torch.cuda is never touched.  It brings its own HIP
