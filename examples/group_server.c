@@ -5,7 +5,7 @@
  * While the readers drain block k the GPU already works on block k+1 (group.h).
  *
  *   cc -I include examples/group_server.c -L libcoolmic-dsp_amd/lib -lcoolmic-dsp-hip \
- *      -Wl,-rpath,$PWD/libcoolmic-dsp_amd/lib -o group_server && ./group_server [streams] [block] [rounds]
+ *      -Wl,-rpath,$PWD/libcoolmic-dsp_amd/lib -o group_server && ./group_server [streams] [block] [rounds] [pull threads]
  *
  * Prints the per-block times of the loop and, for stream 0 and the last stream, what the
  * golden vector G1 of SURVEY 8(c) says a 1 kHz sine at gain 1000/1000 must give.
@@ -30,6 +30,7 @@ int main(int argc, char **argv)
     const unsigned streams = argc > 1 ? (unsigned)atoi(argv[1]) : 1024;
     const size_t block = argc > 2 ? (size_t)atoi(argv[2]) : 4096;
     const unsigned rounds = argc > 3 ? (unsigned)atoi(argv[3]) : 16;
+    const unsigned pull_threads = argc > 4 ? (unsigned)atoi(argv[4]) : 1;   /* the pump's reads of the sources */
     static const uint16_t unity[1] = {1000};
     const size_t nbytes = block * 2;                      /* mono int16 */
     coolmic_group_t *grp = coolmic_group_new(NULL, igloo_RO_NULL, 48000, 1, streams, block, 2);
@@ -43,6 +44,8 @@ int main(int argc, char **argv)
         fprintf(stderr, "no group (no GPU?)\n");
         return 1;
     }
+    if (coolmic_group_set_pull_threads(grp, pull_threads) != COOLMIC_ERROR_NONE)
+        return 1;
     for (s = 0; s < streams; s++) {
         coolmic_snddev_t *dev = coolmic_snddev_new(NULL, igloo_RO_NULL, "sine", NULL, 48000, 1,
                                                    COOLMIC_DSP_SNDDEV_RX, -1);
@@ -75,8 +78,8 @@ int main(int argc, char **argv)
     for (s = 0; s < streams; s++)                          /* the last block */
         if (coolmic_iohandle_read(out[s], buf, nbytes) != (ssize_t)nbytes)
             return 2;
-    printf("streams %u block %zu: pump %.3f ms, readers %.3f ms per block -> %.0f Msamples/s (checksum %llu)\n",
-           streams, block, t_pump / rounds, t_read / rounds,
+    printf("streams %u block %zu pull threads %u: pump %.3f ms, readers %.3f ms per block -> %.0f Msamples/s (checksum %llu)\n",
+           streams, block, pull_threads, t_pump / rounds, t_read / rounds,
            (double)streams * block / ((t_pump + t_read) / rounds * 1e-3) / 1e6, sum);
     for (s = 0; s < streams; s += streams - 1 ? streams - 1 : 1) {
         coolmic_vumeter_result_t res;

@@ -69,6 +69,13 @@ coolmic_iohandle_t *coolmic_group_get_iohandle(coolmic_group_t *self, unsigned i
  * in flight is in the queues then), negative on error. */
 int                 coolmic_group_pump(coolmic_group_t *self);
 
+/* The pull of a pump -- one read per upstream handle -- spread over `threads` threads (the pumping thread
+ * counts; 0 or 1: the pumping thread alone, which is how a group starts).  The handles of DIFFERENT streams
+ * are then read at the same time, each stream's own handle still by one thread at a time and once per pump:
+ * fine for the sources of this library and for callbacks that keep their state per stream, as the reference's
+ * pipelines do with one thread each (ref: src/simple.c:292-310).  COOLMIC_ERROR_INVAL above 64. */
+int                 coolmic_group_set_pull_threads(coolmic_group_t *self, unsigned int threads);
+
 /* VU window of one stream since its last result; COOLMIC_ERROR_INVAL while it holds no frame */
 int                 coolmic_group_vumeter_result(coolmic_group_t *self, unsigned int slot,
                                                  coolmic_vumeter_result_t *result);

@@ -200,6 +200,7 @@ SIGNATURES = {
     "coolmic_group_set_eq": (C.c_int, [_vp, C.c_int, C.c_uint, _vp]),
     "coolmic_group_get_iohandle": (_vp, [_vp, C.c_uint]),
     "coolmic_group_pump": (C.c_int, [_vp]),
+    "coolmic_group_set_pull_threads": (C.c_int, [_vp, C.c_uint]),
     "coolmic_group_vumeter_result": (C.c_int, [_vp, C.c_uint, _P(VuResult)]),
     "coolmic_group_streams": (C.c_uint, [_vp]),
 }
@@ -821,6 +822,9 @@ class Group:
 
     def pump(self):
         return lib.coolmic_group_pump(self.ptr)
+
+    def set_pull_threads(self, threads):
+        return lib.coolmic_group_set_pull_threads(self.ptr, threads)
 
     def vumeter_result(self, slot):
         r = VuResult()

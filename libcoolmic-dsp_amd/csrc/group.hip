@@ -12,6 +12,7 @@
 #include "host_internal.h"
 #include <coolmic-dsp/group.h>
 #include <coolmic_hip.h>
+#include "work_pool.h"
 
 // A block's PCM never leaves the pinned set it was produced in until a reader copies it out: the
 // batch has no PCM arrays of its own (CMHIP_EXTSLOTS); the group owns two input sets and a ring of
@@ -54,6 +55,7 @@ struct coolmic_group {
     std::vector<uint32_t> *nframes;          // frames per stream of the block being pulled
     std::vector<uint32_t> *flight;           // ... of the block on the GPU
     bool in_flight;                          // a block's launch is queued
+    WorkPool *pullers;                       // helpers for the pull of a pump (coolmic_group_set_pull_threads)
 };
 
 struct GroupHandle {
@@ -64,6 +66,7 @@ struct GroupHandle {
 static void group_destroy(void *self)
 {
     coolmic_group_t *g = (coolmic_group_t *)self;
+    delete g->pullers;
     if (g->streams) {
         for (auto &s : *g->streams)
             coolmic_ro_unref(s.source);
@@ -254,6 +257,56 @@ static void group_vacate(coolmic_group_t *self, unsigned set)
     (*self->out_users)[set] = 0;
 }
 
+// the pull of streams [lo, hi) of one pump: one iohandle read per stream straight into its slot of the
+// input set, framed like ref: src/transform.c:126-165.  Streams share nothing here (slot, carry and
+// frame count are the stream's own), so ranges may run on different threads.
+struct GroupPull {
+    coolmic_group_t *g;
+    int16_t *h_in;
+    size_t framesize, block_bytes, queue_cap;
+};
+
+static void group_pull_range(void *arg, unsigned lo, unsigned hi)
+{
+    const GroupPull *p = (const GroupPull *)arg;
+    coolmic_group_t *self = p->g;
+    for (size_t i = lo; i < hi; i++) {
+        GroupStream &s = (*self->streams)[i];
+        (*self->nframes)[i] = 0;
+        const size_t coming = self->in_flight ? (size_t)(*self->flight)[i] * p->framesize : 0;
+        if (s.pending + coming + p->block_bytes > p->queue_cap)
+            continue;                          // this stream's reader is behind: no read-ahead
+        unsigned char *dst = (unsigned char *)(p->h_in + i * self->stride);
+        size_t have = 0;
+        if (s.carry_fill) {
+            memcpy(dst, s.carry, s.carry_fill);
+            have = s.carry_fill;
+            s.carry_fill = 0;
+        }
+        const ssize_t got = coolmic_iohandle_read(s.source, dst + have, p->block_bytes - have);
+        if (got > 0)
+            have += (size_t)got;
+        const size_t tail = have % p->framesize;
+        if (tail) {
+            memcpy(s.carry, dst + have - tail, tail);
+            s.carry_fill = tail;
+            have -= tail;
+        }
+        (*self->nframes)[i] = (uint32_t)(have / p->framesize);
+    }
+}
+
+extern "C" int coolmic_group_set_pull_threads(coolmic_group_t *self, unsigned int threads)
+{
+    if (!self)
+        return COOLMIC_ERROR_FAULT;
+    if (threads > 64)
+        return COOLMIC_ERROR_INVAL;
+    delete self->pullers;                    // (no pump is under way: the group is driven by one thread)
+    self->pullers = threads > 1 ? new WorkPool(threads - 1) : nullptr;     // the pumping thread pulls too
+    return COOLMIC_ERROR_NONE;
+}
+
 // One block: pull from every source straight into the input set the kernel will read, then (the
 // previous block being home) launch this one on that set and the next output set, and return --
 // the GPU works while the caller reads and the next pump pulls.  The block's PCM can be read with
@@ -272,31 +325,14 @@ extern "C" int coolmic_group_pump(coolmic_group_t *self)
     uint32_t most = 0;
     int delivered = 0;
 
-    // 1. pull: one iohandle read per stream, framed like ref: src/transform.c:126-165
+    // 1. pull: one iohandle read per stream (group_pull_range), on this thread or spread over the helpers
+    const GroupPull pull = {self, h_in, framesize, block_bytes, queue_cap};
+    if (self->pullers && n >= 16)
+        self->pullers->run(group_pull_range, (void *)&pull, (unsigned)n, 8);
+    else
+        group_pull_range((void *)&pull, 0, (unsigned)n);
     for (size_t i = 0; i < n; i++) {
-        GroupStream &s = (*self->streams)[i];
-        (*self->nframes)[i] = 0;
-        const size_t coming = self->in_flight ? (size_t)(*self->flight)[i] * framesize : 0;
-        if (s.pending + coming + block_bytes > queue_cap)
-            continue;                          // this stream's reader is behind: no read-ahead
-        unsigned char *dst = (unsigned char *)(h_in + i * self->stride);
-        size_t have = 0;
-        if (s.carry_fill) {
-            memcpy(dst, s.carry, s.carry_fill);
-            have = s.carry_fill;
-            s.carry_fill = 0;
-        }
-        const ssize_t got = coolmic_iohandle_read(s.source, dst + have, block_bytes - have);
-        if (got > 0)
-            have += (size_t)got;
-        const size_t tail = have % framesize;
-        if (tail) {
-            memcpy(s.carry, dst + have - tail, tail);
-            s.carry_fill = tail;
-            have -= tail;
-        }
-        const uint32_t fr = (uint32_t)(have / framesize);
-        (*self->nframes)[i] = fr;
+        const uint32_t fr = (*self->nframes)[i];
         if (fr > most)
             most = fr;
         if (fr)

@@ -52,13 +52,14 @@ def test_batch_block_in_c(gpu, oracle, tmp_path):
 def test_group_server_in_c(gpu, golden, tmp_path):
     """A many-stream host loop on the operator API (group.h): 94 blocks of 512 frames of the 48 kHz
     sine at unity gain are golden vector G1 on every stream, however the blocks were pipelined."""
-    lines = _build_and_run(tmp_path, "group_server", 8, 512, 92)
     exp = golden["cases"]["G1"]["vu"]
-    assert lines[0].startswith("streams 8 block 512:")
-    assert len(lines) == 3
-    for line, s in zip(lines[1:], (0, 7)):
-        assert line == "stream %d: frames %d peak %d power %.17g" % (
-            s, exp["frames"], exp["global_peak"], exp["global_power"])
+    for streams, threads in ((8, 1), (40, 4)):           # (the second: the pump's reads spread over four threads)
+        lines = _build_and_run(tmp_path, "group_server", streams, 512, 92, threads)
+        assert lines[0].startswith("streams %d block 512 pull threads %d:" % (streams, threads))
+        assert len(lines) == 3
+        for line, s in zip(lines[1:], (0, streams - 1)):
+            assert line == "stream %d: frames %d peak %d power %.17g" % (
+                s, exp["frames"], exp["global_peak"], exp["global_power"])
 
 
 def test_node_vu_in_c(gpu, oracle, tmp_path):

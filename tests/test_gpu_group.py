@@ -190,3 +190,66 @@ def test_group_slow_readers_and_small_blocks(gpu, oracle):
     for h in handles:
         h.unref()
     grp.unref()
+
+
+@pytest.mark.parametrize("threads", [1, 5])
+def test_group_pull_spread_over_threads(gpu, oracle, threads):
+    """coolmic_group_set_pull_threads: the reads of a pump's upstream handles on several threads -- native
+    sources (the library's own sine device) and callbacks of the host (here Python's) side by side, ragged
+    lengths, pieces of odd sizes.  Every stream's PCM and window as with one thread, i.e. as the oracle's chain."""
+    cm = gpu
+    C, N, block = 1, 40, 700
+    grp = cm.Group(C, N, block, queue_blocks=2)
+    assert grp.set_pull_threads(65) == cm.ERROR_INVAL
+    assert grp.set_pull_threads(threads) == 0
+    rng = np.random.default_rng(55)
+    xs, gains, handles = [], [], []
+    for i in range(N):
+        frames = int(rng.integers(0, 6000))
+        if i % 4 == 0:                                   # a native source: one period of the sine device, repeated
+            dev = cm.Snddev("sine", 48000, 1)
+            src = dev.get_iohandle()
+            dev.unref()
+            rc, period = cm.sine_period(48000)
+            assert rc == 0
+            x = np.tile(period, frames // period.size + 1)[:frames]
+            frames_limit = frames
+        else:
+            x = oracle.lcg(300 + i, frames * C)
+            src = cm.IoHandle.from_bytes(x.tobytes(), chunk=int(rng.choice([0, 3, 64, 1001])))
+            frames_limit = None
+        slot = grp.add_stream(src)
+        src.unref()
+        g = [int(rng.integers(100, 2500))]
+        assert grp.set_master_gain(slot, C, 1000, g) == 0
+        xs.append((x, frames_limit))
+        gains.append(g)
+        handles.append(grp.get_iohandle(slot))
+    got = [b"" for _ in range(N)]
+    active = set(range(N))
+    guard = 0
+    while active and guard < 100000:
+        guard += 1
+        for i in list(active):
+            x, limit = xs[i]
+            want_bytes = 2 * C * x.size
+            if limit is not None:                        # the endless source: read what the test compares, no more
+                left = want_bytes - len(got[i])
+                if left == 0:
+                    active.discard(i)
+                    continue
+                n, data = handles[i].read(min(left, 1400))
+            else:
+                n, data = handles[i].read(4096)
+            assert n >= 0 and n % (2 * C) == 0
+            got[i] += data
+            if limit is None and n == 0 and handles[i].eof() == 1:
+                active.discard(i)
+    assert not active
+    for i in range(N):
+        x, limit = xs[i]
+        want = _expect(oracle, x, C, gains[i], None)
+        assert np.array_equal(np.frombuffer(got[i], np.int16), want), (threads, i)
+    for h in handles:
+        h.unref()
+    grp.unref()

@@ -8,9 +8,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 cm = ge.load_package()
 rounds = 8
-for N, block in ((256, 4096), (1024, 4096), (4096, 1024), (4096, 4096)):
+THREADS = [int(t) for t in os.environ.get("GROUP_PULL_THREADS", "1,4,8").split(",")]
+for N, block, threads in [(n, b, t) for (n, b) in ((256, 4096), (1024, 4096), (4096, 1024), (4096, 4096)) for t in THREADS]:
     C = 2
     grp = cm.Group(C, N, block, queue_blocks=rounds + 2)
+    grp.set_pull_threads(threads)
     hs = []
     for i in range(N):
         dev = cm.Snddev("null", 48000, C)
@@ -38,7 +40,7 @@ for N, block in ((256, 4096), (1024, 4096), (4096, 1024), (4096, 4096)):
     t2 = time.perf_counter()
     assert got == rounds * N * nbytes, (got, rounds * N * nbytes)
     samples = rounds * N * block * C
-    print(f"N={N:5d} block={block:5d}: pump {(t1 - t0) / rounds * 1e3:7.3f} ms per block -> "
+    print(f"N={N:5d} block={block:5d} pull threads={threads}: pump {(t1 - t0) / rounds * 1e3:7.3f} ms per block -> "
           f"{samples / (t1 - t0) / 1e6:8.1f} Msamples/s;  readers (ctypes) {(t2 - t1) / rounds * 1e3:7.2f} ms per block")
     for h in hs:
         h.unref()
