@@ -1,5 +1,10 @@
 // k_eq.hip -- the pipelined equaliser kernel (BASELINE config 3) and its launcher.
 #include "cmhip_device.h"
+#include <type_traits>
+// 0 never, 1 always, 2 (the product) when the launch has an int16 result: see rec_step
+#ifndef CMHIP_EQ_R_INTERLEAVE
+#define CMHIP_EQ_R_INTERLEAVE 2
+#endif
 
 #include <mutex>
 
@@ -390,20 +395,33 @@ void k_eq_pipe(EqArgs a)
                     for (u32 t = 0; t < EP_TB / 4; t++)
                         out[t] = v[t];
                 } else if (__all(cnt == EP_TB)) {
+                    // Where the stores go: left alone the scheduler moves all sixteen to the end of the row.  Kept
+                    // behind their four samples each (a scheduling barrier per store) the runs that produce an
+                    // int16 result take 2.3-3.6 % less and config 3's float planes 0.8 % more (A/B in one process,
+                    // profiles/r03_eq_store_order_ab.txt) -- so the order follows the outputs.  Either way a store
+                    // holds the wave for its 25-50 clk: spacing them does not hide that (NOTES_r03).
+                    auto row = [&](auto spaced) {
 #pragma unroll
-                    for (u32 t = 0; t < EP_TB / 4; t++) {
-                        float4 y = v[t];
-                        if (!(CMHIP_EQ_ABL & 256) || (t & 1u) == 0u) {      // (256: timing only, half the FMAs)
-                            y.x = __builtin_fmaf(d1, h1, __builtin_fmaf(d2, h2, v[t].x));
-                            y.y = __builtin_fmaf(d1, y.x, __builtin_fmaf(d2, h1, v[t].y));
-                            y.z = __builtin_fmaf(d1, y.y, __builtin_fmaf(d2, y.x, v[t].z));
-                            y.w = __builtin_fmaf(d1, y.z, __builtin_fmaf(d2, y.y, v[t].w));
-                            h2 = y.z;
-                            h1 = y.w;
+                        for (u32 t = 0; t < EP_TB / 4; t++) {
+                            float4 y = v[t];
+                            if (!(CMHIP_EQ_ABL & 256) || (t & 1u) == 0u) {      // (256: timing only, half the FMAs)
+                                y.x = __builtin_fmaf(d1, h1, __builtin_fmaf(d2, h2, v[t].x));
+                                y.y = __builtin_fmaf(d1, y.x, __builtin_fmaf(d2, h1, v[t].y));
+                                y.z = __builtin_fmaf(d1, y.y, __builtin_fmaf(d2, y.x, v[t].z));
+                                y.w = __builtin_fmaf(d1, y.z, __builtin_fmaf(d2, y.y, v[t].w));
+                                h2 = y.z;
+                                h1 = y.w;
+                            }
+                            if (!(CMHIP_EQ_ABL & 8) || t == 0)
+                                out[t] = y;
+                            if constexpr (decltype(spaced)::value)
+                                __builtin_amdgcn_sched_barrier(0);
                         }
-                        if (!(CMHIP_EQ_ABL & 8) || t == 0)
-                            out[t] = y;
-                    }
+                    };
+                    if (CMHIP_EQ_R_INTERLEAVE == 1 || (CMHIP_EQ_R_INTERLEAVE == 2 && a.out != nullptr))
+                        row(std::true_type{});
+                    else
+                        row(std::false_type{});
                 } else {
                     // some stream ends inside this block: same arithmetic, but the history of a
                     // lane moves only on its real samples (what lies beyond is never stored)
