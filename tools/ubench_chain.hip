@@ -187,6 +187,47 @@ __global__ void k_rec_pf(float *out, uint64_t *cyc, int iters, float c1, float c
     if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// the recurrence row loop with its results stored to GLOBAL memory instead of LDS (a scratch that stays in L2:
+// rows of 68 floats per lane, as in LDS), reads from LDS as before -- what the issuing wave pays per store there
+template <bool NT>
+__global__ void k_rec_g(float *out, uint64_t *cyc, int iters, float c1, float c2, float *scratch)
+{
+    extern __shared__ float lds[];
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    float *rowp = lds + (wave * 64 + lane) * 68;
+    float *growp = scratch + ((size_t)(blockIdx.x * nw + wave) * 64 + lane) * 68;
+    for (int t = 0; t < 64; t++) rowp[t] = (float)(threadIdx.x & 15) * 1e-3f;
+    __syncthreads();
+    float h1 = 0.f, h2 = 0.f;
+    float4 v[16];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) v[t] = reinterpret_cast<const float4 *>(rowp)[t];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            float4 y;
+            y.x = __builtin_fmaf(c1, h1, __builtin_fmaf(c2, h2, v[t].x));
+            y.y = __builtin_fmaf(c1, y.x, __builtin_fmaf(c2, h1, v[t].y));
+            y.z = __builtin_fmaf(c1, y.y, __builtin_fmaf(c2, y.x, v[t].z));
+            y.w = __builtin_fmaf(c1, y.z, __builtin_fmaf(c2, y.y, v[t].w));
+            h2 = y.z;
+            h1 = y.w;
+            const f32x4 yy = {y.x, y.y, y.z, y.w};
+            if (NT)
+                __builtin_nontemporal_store(yy, reinterpret_cast<f32x4 *>(growp) + t);
+            else
+                reinterpret_cast<f32x4 *>(growp)[t] = yy;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const uint64_t t1 = __builtin_readcyclecounter();
+    float s = h1 + h2;
+    if (s == 0.12345f) out[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
 // barrier cost alone: nothing between the barriers but a few FMAs
 __global__ void k_bar(float *out, uint64_t *cyc, int iters, float c)
 {
@@ -257,6 +298,13 @@ int main()
         CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_pf<B>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_rec_pf<B>), dim3(grid), dim3(THREADS), 2 * (THREADS) * 68 * 4, 0, out, cyc, iters, -0.5f, 0.25f); }, cyc, iters, 128)
     RECPF(false, 64); RECPF(true, 64); RECPF(false, 256); RECPF(true, 256);
+    float *scratch;
+    CHECK(hipMalloc(&scratch, (size_t)grid * 8 * 64 * 68 * 4));
+#define RECG(NT, THREADS) run("rec ldsR=1 GLOBAL W nt=" #NT " threads=" #THREADS, [&] { \
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rec_g<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((k_rec_g<NT>), dim3(grid), dim3(THREADS), (THREADS) * 68 * 4, 0, out, cyc, iters, -0.5f, 0.25f, scratch); }, cyc, iters, 128)
+    RECG(false, 64); RECG(false, 128); RECG(false, 256); RECG(false, 512);
+    RECG(true, 64); RECG(true, 256);
     run("barrier only threads=256", [&] { hipLaunchKernelGGL(k_bar, dim3(grid), dim3(256), 0, 0, out, cyc, iters, 0.5f); }, cyc, iters, 1);
     run("barrier only threads=512", [&] { hipLaunchKernelGGL(k_bar, dim3(grid), dim3(512), 0, 0, out, cyc, iters, 0.5f); }, cyc, iters, 1);
     return 0;
