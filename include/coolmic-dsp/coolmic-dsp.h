@@ -11,6 +11,10 @@
 extern "C" {
 #endif
 
+/* codec names of the encoder stage (not built here; a host's sources name them: ref: coolmic-dsp.h:32-33) */
+#define COOLMIC_DSP_CODEC_VORBIS "audio/ogg; codec=vorbis"
+#define COOLMIC_DSP_CODEC_OPUS   "audio/ogg; codec=opus"
+
 #define COOLMIC_ERROR_NONE              (  0)
 #define COOLMIC_ERROR_GENERIC           ( -1)
 #define COOLMIC_ERROR_NOSYS             ( -8)
@@ -27,11 +31,17 @@ extern "C" {
 #define COOLMIC_ERROR_BADRQC            (-19)
 #define COOLMIC_ERROR_RETRY             (-20)
 
-/* feature names this build can report (ref: coolmic-dsp.h:53-58 for the driver ones) */
-#define COOLMIC_FEATURE_DRIVER_NULL     "driver:null"
-#define COOLMIC_FEATURE_DRIVER_SINE     "driver:sine"
-#define COOLMIC_FEATURE_DRIVER_STDIO    "driver:stdio"
-#define COOLMIC_FEATURE_ACCEL_HIP       "accel:hip/gfx950"
+/* feature names (ref: coolmic-dsp.h:53-58).  Encoders and hardware drivers are the host's: inside the reference's
+ * build their tokens come from its own flags (make dropin HOST_FEATURES=...); the stand-alone library reports the
+ * drivers it brings.  driver:sine and accel:* are this library's additions. */
+#define COOLMIC_FEATURE_ENCODE_OGG_VORBIS   "encode:ogg/vorbis"
+#define COOLMIC_FEATURE_ENCODE_OGG_OPUS     "encode:ogg/opus"
+#define COOLMIC_FEATURE_DRIVER_NULL         "driver:null"
+#define COOLMIC_FEATURE_DRIVER_OSS          "driver:oss"
+#define COOLMIC_FEATURE_DRIVER_OPENSL       "driver:opensl"
+#define COOLMIC_FEATURE_DRIVER_STDIO        "driver:stdio"
+#define COOLMIC_FEATURE_DRIVER_SINE         "driver:sine"
+#define COOLMIC_FEATURE_ACCEL_HIP           "accel:hip/gfx950"
 
 /* static text for an error number (ref: src/coolmic-dsp.c, coolmic_error2string) */
 const char *coolmic_error2string(const int error);

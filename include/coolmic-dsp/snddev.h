@@ -23,6 +23,10 @@ extern "C" {
 #define COOLMIC_DSP_SNDDEV_DRIVER_NULL   "null"
 #define COOLMIC_DSP_SNDDEV_DRIVER_SINE   "sine"
 #define COOLMIC_DSP_SNDDEV_DRIVER_STDIO  "stdio"    /* raw PCM file replay; device = file name */
+/* hardware drivers of the reference: known by name, not built into the stand-alone library (coolmic_snddev_new
+ * returns NULL for them); inside the reference's build its own snddev*.c serve them */
+#define COOLMIC_DSP_SNDDEV_DRIVER_OSS    "oss"
+#define COOLMIC_DSP_SNDDEV_DRIVER_OPENSL "opensl"
 
 #define COOLMIC_DSP_SNDDEV_RX    0x0001
 #define COOLMIC_DSP_SNDDEV_TX    0x0002

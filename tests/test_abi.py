@@ -156,3 +156,36 @@ def test_host_feature_tokens_of_the_dropin_build():
     toks = lib.coolmic_features().split(b" ")
     assert toks[0] == b"features" and b"accel:hip/gfx950" in toks and b"encode:ogg/vorbis" in toks
     assert lib.coolmic_feature_check(b"encode:ogg/opus") == 1 and lib.coolmic_feature_check(b"driver:sine") == 0
+
+
+def _macros(path):
+    """object-like macros of a header: name -> replacement text (comments and spacing stripped)"""
+    import re
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"^[ \t]*#[ \t]*define[ \t]+([A-Za-z_][A-Za-z_0-9]*)(?![A-Za-z_0-9(])[ \t]*(.*)$", text, flags=re.M):
+        out[m.group(1)] = " ".join(m.group(2).split())
+    return out
+
+
+def test_public_macros_equal_the_references():
+    """A host's sources compile against these headers instead of the reference's: every object-like macro the
+    reference's versions of the shipped headers define (error numbers, feature tokens, driver names, limits,
+    log levels ...) is defined here with the same replacement text.  (Include guards aside; function-like
+    macros are compared by test_headers_compile_as_c_and_cxx's clients.)"""
+    if not os.path.isdir(os.path.join(REFERENCE, "include", "coolmic-dsp")):
+        pytest.skip("the reference headers are not on this machine")
+    missing, different = [], []
+    for h in ("coolmic-dsp.h", "iohandle.h", "transform.h", "vumeter.h", "tee.h", "snddev.h", "logging.h", "util.h"):
+        ref = _macros(os.path.join(REFERENCE, "include", "coolmic-dsp", h))
+        own = _macros(os.path.join(ROOT, "include", "coolmic-dsp", h))
+        for name, value in ref.items():
+            if name.startswith("__COOLMIC_DSP_") and value == "":
+                continue                                 # include guard
+            if name not in own:
+                missing.append((h, name))
+            elif own[name] != value:
+                different.append((h, name, value, own[name]))
+    assert not missing, missing
+    assert not different, different
