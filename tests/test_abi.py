@@ -189,3 +189,38 @@ def test_public_macros_equal_the_references():
                 different.append((h, name, value, own[name]))
     assert not missing, missing
     assert not different, different
+
+
+def _prototypes(path):
+    """coolmic_* function declarations of a header: name -> (return type, parameter list), spacing normalised,
+    attributes dropped"""
+    import re
+    t = open(path).read()
+    t = re.sub(r"/\*.*?\*/", " ", t, flags=re.S)
+    t = re.sub(r"//.*", " ", t)
+    t = re.sub(r"^\s*#.*$", " ", t, flags=re.M)
+    t = re.sub(r"__attribute__\s*\(\((?:[^()]|\([^()]*\))*\)\)", " ", t)
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z_0-9 \*\n\t]*?)\b(coolmic_[a-z0-9_]+)\s*\(([^;{]*)\)\s*;", t):
+        ret, name, args = " ".join(m.group(1).split()), m.group(2), " ".join(m.group(3).split())
+        if "typedef" in ret:
+            continue
+        tight = lambda x: re.sub(r"\s*([\*\(\),])\s*", r"\1", x)
+        out[name] = (tight(ret), tight(args))
+    return out
+
+
+def test_prototypes_equal_the_references():
+    """every function the reference's versions of the shipped headers declare is declared here with the same
+    return type and the same parameter list, token for token (ref: include/coolmic-dsp/*.h)"""
+    if not os.path.isdir(os.path.join(REFERENCE, "include", "coolmic-dsp")):
+        pytest.skip("the reference headers are not on this machine")
+    seen = 0
+    for h in ("coolmic-dsp.h", "iohandle.h", "transform.h", "vumeter.h", "tee.h", "snddev.h", "logging.h", "util.h"):
+        ref = _prototypes(os.path.join(REFERENCE, "include", "coolmic-dsp", h))
+        own = _prototypes(os.path.join(ROOT, "include", "coolmic-dsp", h))
+        for name, proto in ref.items():
+            assert name in own, (h, name)
+            assert own[name] == proto, (h, name, proto, own[name])
+            seen += 1
+    assert seen >= 28                                     # (the eight headers declare 28 functions)
