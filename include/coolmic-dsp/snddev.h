@@ -34,6 +34,19 @@ extern "C" {
 
 typedef struct coolmic_snddev coolmic_snddev_t;
 
+/* What a driver fills in for the device object (ref: include/coolmic-dsp/snddev.h:55-68): declared so that a
+ * host's driver sources compile against this header.  The stand-alone library has its three sources built in and
+ * no registry for further drivers; inside the reference's build its own snddev.c, which owns that registry,
+ * stays. */
+typedef struct coolmic_snddev_driver coolmic_snddev_driver_t;
+struct coolmic_snddev_driver {
+    int (*free)(coolmic_snddev_driver_t *dev);
+    ssize_t (*read)(coolmic_snddev_driver_t *dev, void *buffer, size_t len);         /* capture */
+    ssize_t (*write)(coolmic_snddev_driver_t *dev, const void *buffer, size_t len);  /* playback */
+    int userdata_i;                    /* the driver's own */
+    void *userdata_vp;
+};
+
 /* NULL for rate/channels/flags of 0, an unknown driver, or a driver that refuses
  * the format (sine: mono only, rate must be 8/16/24/32/44/44.1/48/96 kHz; stdio: the file
  * must open -- "rb" for RX, "wb" for TX, "w+b" for both) */
