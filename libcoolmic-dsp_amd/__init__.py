@@ -211,8 +211,9 @@ for _name, (_res, _args) in SIGNATURES.items():
         _fn.argtypes = _args
 
 # not in a public header: host-logic test hooks
-lib.cmhip_test_magic.restype = None
-lib.cmhip_test_magic.argtypes = [C.c_uint16, _P(C.c_uint32), _P(C.c_uint32)]
+if hasattr(lib, "cmhip_test_gain_consts"):      # (an older build loaded by tools/ab_two_libs.py has another hook)
+    lib.cmhip_test_gain_consts.restype = None
+    lib.cmhip_test_gain_consts.argtypes = [C.c_uint16, C.c_uint16, _P(C.c_uint16), _P(C.c_uint32)]
 lib.cmhip_test_merge_windows.restype = C.c_int
 lib.cmhip_test_merge_windows.argtypes = [_P(C.c_uint64), C.c_uint, C.c_uint, C.c_uint, _P(VuResult)]
 lib.cmhip_debug_run_count.restype = C.c_ulonglong
@@ -254,10 +255,12 @@ def last_error():
     return lib.cmhip_last_error().decode()
 
 
-def magic(scale):
-    m, s = C.c_uint32(), C.c_uint32()
-    lib.cmhip_test_magic(scale, C.byref(m), C.byref(s))
-    return m.value, s.value
+def gain_consts(gain, scale):
+    """Test hook: the division constants the kernels use for gain / scale -- integer part mi and fraction mf with
+    floor(|x| * gain / scale) == |x| * mi + ((|x| * mf) >> 32) for every |x| <= 32768 (StreamParam, cmhip_internal.h)."""
+    mi, mf = C.c_uint16(), C.c_uint32()
+    lib.cmhip_test_gain_consts(gain, scale, C.byref(mi), C.byref(mf))
+    return mi.value, mf.value
 
 
 def merge_windows(windows, channels, rate=48000):

@@ -178,8 +178,6 @@ struct cmhip_batch {
     unsigned long long *d_dbg;             // 64 words, written only by diagnostic builds
 
     std::vector<StreamParam> h_param;
-    std::vector<GainShort> h_gshort;       // the shorter gain forms (read-only mono / stereo runs)
-    GainShort *d_gshort;
     std::vector<uint16_t> h_scale;         // the reference's master_gain_scale per stream
     std::vector<uint16_t> h_gain;          // [S][16]
     bool param_dirty;
@@ -249,48 +247,39 @@ static inline int use(cmhip_batch_t *b)
     return COOLMIC_ERROR_NONE;
 }
 
-// magic for floor(n/scale), n < 2^31, via n2 = 2n: q = mulhi(n2, magic) >> shift.
-// With l = ceil(log2 scale) and magic = ceil(2^(31+l)/scale) the error term
-// magic*scale - 2^(31+l) is below scale <= 2^l, which is the Granlund-Montgomery
-// condition for exactness over all n < 2^31.  magic < 2^32 because scale > 2^(l-1).
-static void host_magic(uint16_t scale, uint32_t *magic, uint32_t *shift)
+// The division constants of one gain (StreamParam): gain = mi * scale + r, mf = ceil(r * 2^32 / scale).
+// mf < 2^32 because r <= scale - 1; mi <= 65535.
+static void host_gain_consts(uint16_t gain, uint16_t scale, uint16_t *mi, uint32_t *mf)
 {
-    uint32_t l = 0;
-    while ((1u << l) < (uint32_t)scale)
-        l++;
-    const unsigned __int128 num = (unsigned __int128)1 << (31 + l);
-    const unsigned __int128 m = (num + scale - 1) / scale;
-    *magic = (uint32_t)m;
-    *shift = l;
+    const uint32_t r = (uint32_t)gain % scale;
+    *mi = (uint16_t)((uint32_t)gain / scale);
+    *mf = (uint32_t)((((uint64_t)r << 32) + scale - 1u) / scale);
 }
 
 static void rebuild_param(cmhip_batch_t *b, unsigned int s)
 {
     StreamParam &p = b->h_param[s];
-    GainShort &q = b->h_gshort[s];
-    q = GainShort{};
     const uint16_t scale = b->h_scale[s];
     bool unity = scale != 0;                // trunc(x * g / g) == x: same as disabled
     for (unsigned c = 0; unity && c < b->d.channels; c++)
         unity = b->h_gain[(size_t)s * MAX_CH + c] == scale;
     if (scale == 0 || unity) {              // disabled: identity through the same arithmetic
-        host_magic(1, &p.magic, &p.shift);
-        for (unsigned c = 0; c < MAX_CH; c++)
-            p.gain2[c] = 2u;
-        q.mode = GAIN_IDENTITY;
+        for (unsigned c = 0; c < MAX_CH; c++) {
+            p.mi[c] = 1;
+            p.mf[c] = 0;
+        }
+        p.mode = GAIN_IDENTITY;
     } else {
-        host_magic(scale, &p.magic, &p.shift);
         bool below = true;
         for (unsigned c = 0; c < MAX_CH; c++) {
-            const uint32_t g = b->h_gain[(size_t)s * MAX_CH + c];
-            p.gain2[c] = 2u * g;
-            // ceil(g * 2^32 / scale); below 2^32 exactly when g < scale
-            q.kmul[c] = g < scale ? (uint32_t)((((uint64_t)g << 32) + scale - 1) / scale) : 0u;
+            const uint16_t g = b->h_gain[(size_t)s * MAX_CH + c];
+            host_gain_consts(g, scale, &p.mi[c], &p.mf[c]);
             if (c < b->d.channels && g >= scale)
                 below = false;
         }
-        q.mode = below ? GAIN_BELOW_SCALE : GAIN_GENERAL;
+        p.mode = below ? GAIN_BELOW_SCALE : GAIN_GENERAL;
     }
+    p.mi01 = (uint32_t)p.mi[0] | ((uint32_t)p.mi[1] << 16);
     bool ident = true;
     for (unsigned c = 0; c < b->d.channels; c++)
         ident = ident && p.chmap[c] == c;
@@ -332,7 +321,6 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     }
     (void)hipFree(b->d_f32);
     (void)hipFree(b->d_param);
-    (void)hipFree(b->d_gshort);
     for (int i = 0; i < 3; i++)
         (void)hipFree(b->d_vu2[i]);
     delete b->pool;
@@ -402,7 +390,6 @@ static double place_probe_ms(cmhip_batch_t *b, const void *src, void *dst, hipEv
     a.out = (int16_t *)dst;
     a.f32 = b->d_f32;
     a.param = b->d_param;
-    a.gshort = b->d_gshort;
     a.vu = (b->d.flags & CMHIP_VU) ? b->d_vu : nullptr;
     a.frames = (uint32_t)b->d.max_frames;
     a.streams = b->d.streams;
@@ -633,7 +620,6 @@ static int batch_init(cmhip_batch_t *b)
         HIP_TRY(hipMemsetAsync(b->d_f32, 0, fbytes, b->stream));
     }
     HIP_TRY(hipMalloc((void **)&b->d_param, S * sizeof(StreamParam)));
-    HIP_TRY(hipMalloc((void **)&b->d_gshort, S * sizeof(GainShort)));
     for (int i = 0; i < 3; i++) {
         HIP_TRY(hipMalloc((void **)&b->d_vu2[i], S * sizeof(VuState)));
         HIP_TRY(hipMemsetAsync(b->d_vu2[i], 0, S * sizeof(VuState), b->stream));
@@ -677,7 +663,6 @@ static int batch_init(cmhip_batch_t *b)
         HIP_TRY(hipEventCreateWithFlags(&b->stage_ev[i], hipEventDisableTiming));
 
     b->h_param.assign(S, StreamParam{});
-    b->h_gshort.assign(S, GainShort{});
     b->h_scale.assign(S, 0);
     b->h_gain.assign(S * MAX_CH, 0);
     for (size_t s = 0; s < S; s++) {
@@ -730,7 +715,6 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->done_flagged = false;
     b->d_f32 = nullptr;
     b->d_param = nullptr;
-    b->d_gshort = nullptr;
     b->d_vu = nullptr;
     b->d_vu2[0] = b->d_vu2[1] = b->d_vu2[2] = nullptr;
     b->cur = 0;
@@ -803,10 +787,11 @@ extern "C" int cmhip_debug_read(cmhip_batch_t *b, unsigned long long *out)
 static std::atomic<unsigned long long> g_runs{0};
 extern "C" unsigned long long cmhip_debug_run_count(void) { return g_runs.load(); }
 
-// test hook: the division constants for a scale (host logic, needs no GPU)
-extern "C" void cmhip_test_magic(uint16_t scale, uint32_t *magic, uint32_t *shift)
+// test hook: the division constants of a gain (host logic, needs no GPU)
+extern "C" void cmhip_test_gain_consts(uint16_t gain, uint16_t scale, uint16_t *mi, uint32_t *mf)
 {
-    host_magic(scale, magic, shift);
+    if (scale && mi && mf)
+        host_gain_consts(gain, scale, mi, mf);
 }
 
 // ---------------------------------------------------------------------------
@@ -1225,12 +1210,10 @@ static int flush_params(cmhip_batch_t *b)
             if (!p.map_identity)
                 b->all_identity = false;
         b->all_gain_identity = true;
-        for (const auto &q : b->h_gshort)
-            if (q.mode != GAIN_IDENTITY)
+        for (const auto &p : b->h_param)
+            if (p.mode != GAIN_IDENTITY)
                 b->all_gain_identity = false;
         HIP_TRY(hipMemcpyAsync(b->d_param, b->h_param.data(), b->h_param.size() * sizeof(StreamParam),
-                               hipMemcpyHostToDevice, b->stream));
-        HIP_TRY(hipMemcpyAsync(b->d_gshort, b->h_gshort.data(), b->h_gshort.size() * sizeof(GainShort),
                                hipMemcpyHostToDevice, b->stream));
         b->param_dirty = false;
     }
@@ -1357,8 +1340,7 @@ static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per
         a.out = (b->d.flags & CMHIP_OUT_PCM) ? slots_out : nullptr;
         a.f32 = b->d_f32;
         a.param = b->d_param;
-        a.gshort = b->d_gshort;
-        a.vu = vu ? window : nullptr;
+            a.vu = vu ? window : nullptr;
         a.nframes = frames_per_stream ? b->d_nframes : nullptr;
         a.frames = (uint32_t)frames;
         a.streams = b->d.streams;

@@ -75,15 +75,26 @@ __device__ __forceinline__ u32 pk_max(u32 a, u32 b)
 }
 
 // one dword = two samples: returns the packed magnitudes after gain + saturation,
-// `out` receives the packed signed result
-__device__ __forceinline__ u32 gain2(u32 w, u32 g2lo, u32 g2hi, u32 magic, u32 shift, u32 &out)
+// `out` receives the packed signed result.  floor(|x| * gain / scale) = |x| * mi + mulhi(|x|, mf)
+// (StreamParam): per sample one v_mul_hi_u32 and one v_mad_u32_u16, which takes the magnitude and the
+// integer part straight from the halves of their packed dwords (mipk = mi of the low half | mi of the
+// high half << 16).  UNIFORM: the gains are the same in every lane (a wave works on one stream and the
+// dword halves have fixed channels: mono, stereo) and sit in SGPRs.
+template <bool UNIFORM>
+__device__ __forceinline__ u32 gain2(u32 w, u32 mipk, u32 mflo, u32 mfhi, u32 &out)
 {
     const u32 sg = pk_sign(w);
     const u32 aw = pk_sub(w ^ sg, sg);                       // |x| per half (u16, 32768 ok)
-    const u32 n0 = __umul24(aw & 0xffffu, g2lo);             // 2*|x|*gain < 2^32
-    const u32 n1 = __umul24(aw >> 16, g2hi);
-    const u32 q0 = __umulhi(n0, magic) >> shift;             // floor(|x|*gain/scale)
-    const u32 q1 = __umulhi(n1, magic) >> shift;
+    const u32 h0 = __umulhi(aw & 0xffffu, mflo);
+    const u32 h1 = __umulhi(aw >> 16, mfhi);
+    u32 q0, q1;                                              // < 2^31: 32768 * 65535 + 32767
+    if constexpr (UNIFORM) {
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v"(q0) : "v"(aw), "s"(mipk), "v"(h0));
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(q1) : "v"(aw), "s"(mipk), "v"(h1));
+    } else {
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v"(q0) : "v"(aw), "v"(mipk), "v"(h0));
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(q1) : "v"(aw), "v"(mipk), "v"(h1));
+    }
     u32 qw = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pk_u16(q0, q1));   // saturates at 65535
     qw = pk_min(qw, pk_sub(0x7fff7fffu, sg));                // 32767, or 32768 for negatives
     out = pk_sub(qw ^ sg, sg);
@@ -96,7 +107,7 @@ __device__ __forceinline__ u32 gain2_below(u32 w, u32 klo, u32 khi, u32 &out)
 {
     const u32 sg = pk_sign(w);
     const u32 aw = pk_sub(w ^ sg, sg);
-    const u32 q0 = __umulhi(aw & 0xffffu, klo);              // floor(|x|*gain/scale), exact (StreamParam)
+    const u32 q0 = __umulhi(aw & 0xffffu, klo);              // floor(|x|*gain/scale): the mi = 0 case (StreamParam)
     const u32 q1 = __umulhi(aw >> 16, khi);
     const u32 qw = __builtin_amdgcn_perm(q1, q0, 0x05040100u);   // both below 2^15: low halves side by side
     out = pk_sub(qw ^ sg, sg);

@@ -12,31 +12,33 @@ constexpr unsigned MAX_CH = 16;
 constexpr unsigned MAX_EQ = 4;
 
 // Per-stream transform parameters, rebuilt on the host whenever a setter runs.
-// Division by `scale` is done on magnitudes: with n2 = |x| * gain2[c] (= 2*|x|*gain,
-// below 2^32) the quotient floor(|x|*gain/scale) is mulhi(n2, magic) >> shift, exact
-// for every |x| <= 32768, gain <= 65535, scale in 1..65535 (host_magic() proves the
-// bound).  A disabled gain (scale 0 in the reference, ref: src/transform.c:107-108)
-// is stored as gain 1 / scale 1, which is the identity through the same code.
-struct StreamParam {
-    uint32_t magic;            // ceil(2^(31+shift) / scale)
-    uint32_t shift;            // ceil(log2(scale))
+// The reference's q = trunc(x * gain / scale) (ref: src/transform.c:111-119) is done on magnitudes with
+// the division split at the integer part of the gain:
+//     gain = mi * scale + r   (r < scale),   mf = ceil(r * 2^32 / scale)   (< 2^32 because r <= scale - 1)
+//     floor(|x| * gain / scale) = |x| * mi + mulhi(|x|, mf)
+// exact for every |x| <= 32768, gain <= 65535, scale in 1..65535: with e = mf * scale - r * 2^32 in
+// [0, scale) the product |x| * mf / 2^32 lies |x| * e / (scale * 2^32) < 2^31 / (scale * 2^32) < 1 / scale
+// above |x| * r / scale, which is itself at least 1 / scale below the next integer when it is not one
+// (cmhip_test_gain_consts / test_division_constants_are_exact prove it per class of gain and scale).
+// Two VALU instructions per sample (v_mul_hi_u32, v_mad_u32_u16) instead of the three of a division
+// by magic number and shift.  A disabled gain (scale 0 in the reference, ref: src/transform.c:107-108) is
+// stored as mi 1 / mf 0, the identity through the same code.
+//
+// mode names the shorter forms the read-only runs take where the VALU binds (a VU window and no PCM
+// result).  GAIN_IDENTITY: the gain is disabled or every gain equals the scale -- the magnitudes are the
+// samples' own.  GAIN_BELOW_SCALE: every gain of the stream is below its scale -- mi is 0 everywhere, one
+// v_mul_hi_u32 per sample, and the quotient never reaches the saturation limits.  GAIN_GENERAL: the rest.
+// 128 bytes, one cache line per stream (round 3 kept the short forms in a table of their own, 96 + 68 bytes).
+struct alignas(128) StreamParam {
+    uint32_t mode;             // GAIN_GENERAL / GAIN_BELOW_SCALE / GAIN_IDENTITY
     uint32_t perm2;            // stereo channel map as a v_perm_b32 selector
     uint32_t map_identity;     // 1 when chmap is the identity
-    uint32_t gain2[MAX_CH];    // 2 * gain[c]
+    uint32_t mi01;             // mi[0] | mi[1] << 16: what the mono / stereo kernels need sits in the first 32 bytes
+    uint32_t mf[MAX_CH];       // ceil((gain[c] % scale) * 2^32 / scale)
+    uint16_t mi[MAX_CH];       // gain[c] / scale
     uint8_t  chmap[MAX_CH];    // out channel c reads in channel chmap[c]
 };
-
-// Shorter forms of the same arithmetic for the runs that the VALU binds (a VU window and no PCM
-// result; mono / stereo: k_run_fast, any other channel count: k_run_rows).  mode 2: the gain is disabled or every gain equals the scale -- the magnitudes
-// are the samples' own.  mode 1: every gain of the stream is below its scale -- with
-// kmul[c] = ceil(gain[c] * 2^32 / scale) the quotient floor(|x|*gain/scale) is mulhi(|x|, kmul[c]) for
-// every |x| <= 32768 (the error term |x| * (kmul*scale - gain*2^32) stays below 2^31), and it never
-// reaches the saturation limits.  mode 0: anything else, the general form of StreamParam.
-// (A table of its own: growing StreamParam from 96 to 168 bytes cost the config-2 kernel 2-4 %.)
-struct GainShort {
-    uint32_t mode;
-    uint32_t kmul[MAX_CH];
-};
+static_assert(sizeof(StreamParam) == 128, "one line per stream");
 constexpr uint32_t GAIN_GENERAL = 0, GAIN_BELOW_SCALE = 1, GAIN_IDENTITY = 2;
 
 // Per-stream VU window, all 64-bit so that every update is an integer atomic
@@ -71,7 +73,6 @@ struct RunArgs {
     int16_t       *out;            // may equal in; nullptr: PCM not written
     float         *f32;            // planar float output or nullptr
     const StreamParam *param;
-    const GainShort *gshort;       // per stream, for the read-only mono / stereo runs
     VuState       *vu;             // nullptr: no VU
     const uint32_t *nframes;       // per-stream frame counts or nullptr
     uint32_t       frames;         // uniform count when nframes == nullptr

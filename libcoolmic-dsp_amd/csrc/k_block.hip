@@ -10,7 +10,7 @@
 //     SGPRs and the waves share nothing while they work (the mono / stereo runs that write
 //     PCM and keep a window put four of them into a workgroup that merges their window
 //     sums in LDS at the very end: a quarter of the global atomics);
-//   * exact integer arithmetic only: 24-bit multiplies, one mul_hi for the division,
+//   * exact integer arithmetic only: one mul_hi and one 24-bit multiply-add for the division,
 //     64-bit integer atomics for the VU window (order independent => bit exact).
 //
 // Reference semantics restated (never copied):
@@ -41,37 +41,28 @@ struct FastShare {
     u32 arrived;
 };
 
+// window position: read from one slot of VuState::samples, the stream's first tile writes the other
+__device__ __forceinline__ u64 window_base(const RunArgs &a, VuState *vs, u32 k, u32 nsamp)
+{
+    const u64 base = vs->samples[a.parity];
+    if (k == 0 && (threadIdx.x & 63u) == 0)
+        vs->samples[a.parity ^ 1u] = base + nsamp;
+    return base;
+}
+
 template <int C, bool WRITE_PCM, bool WRITE_F32, bool DO_VU, int U, bool FULL>
 __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 nsamp, u32 nfull, u32 ntail,
-                                          u64 base, VuState *vs, FastShare *share)
+                                          u64 base, VuState *vs, FastShare *share, const int16_t *a_in,
+                                          int16_t *a_out, u64 a_stride)
 {
     constexpr u32 TILE_U = U;
     constexpr u32 TILE_VEC = 64 * TILE_U;
     const u32 lane = threadIdx.x & 63u;
     const u32 v0 = k * TILE_VEC;
-    (void)nsamp;
 
-    const StreamParam *p = a.param + s;
-    const u32 magic = p->magic, shift = p->shift, perm2 = p->perm2;
-    // Stereo, nothing but the VU window asked for, and the stream's map the identity or the swap:
-    // the samples stay where they are and the two halves of a dword change roles instead (sw = 1:
-    // the low half is output channel 1) -- one v_perm_b32 per dword less.  A map that repeats a
-    // channel, and every run that writes PCM or floats, permutes as before.
-    constexpr bool ROLES = C == 2 && DO_VU && !WRITE_PCM && !WRITE_F32;
-    const bool keep = ROLES && (perm2 == 0x03020100u || perm2 == 0x01000302u);
-    const u32 sw = keep && perm2 == 0x01000302u ? 1u : 0u;
-    const u32 g2lo = p->gain2[sw ? C - 1 : 0], g2hi = p->gain2[sw ? 0 : C - 1];    // gains of the two dword halves
-    // StreamParam::mode: the general form serves every stream; the shorter ones are taken where the
-    // VALU binds (a VU window, no PCM result, whole tiles).  The branch comes after the loads are out.
-    constexpr bool MODES = DO_VU && !WRITE_PCM && FULL;
-    const GainShort *gs = a.gshort + (MODES ? s : 0u);
-    const u32 mode = MODES ? uniform(gs->mode) : GAIN_GENERAL;
-    const u32 klo = MODES ? gs->kmul[sw ? C - 1 : 0] : 0u;
-    const u32 khi = MODES ? gs->kmul[sw ? 0 : C - 1] : 0u;
-
-    const int16_t *ins = a.in + (u64)s * a.stride;
+    const int16_t *ins = a_in + (u64)s * a_stride;
     const u32x4 *src = reinterpret_cast<const u32x4 *>(ins);
-    int16_t *outs = WRITE_PCM ? a.out + (u64)s * a.stride : nullptr;
+    int16_t *outs = WRITE_PCM ? a_out + (u64)s * a_stride : nullptr;
     u32x4 *dst = reinterpret_cast<u32x4 *>(outs);
     float *f32s = WRITE_F32 ? a.f32 + (u64)s * a.plane * C : nullptr;
 
@@ -97,6 +88,35 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
             }
         }
     }
+
+    // ---- the stream's parameters, read only now: the tile's loads above depend on kernel arguments (and the
+    // window position, which run_fast reads first) alone and are on their way.  (Scalar loads return out of order, so a wait for the kernel arguments is a wait for
+    // every scalar load issued by then: with the parameter reads ahead of the tile's loads each of these
+    // short-lived waves paid the parameter line's miss BEFORE its loads went out -- 8 % of a config-4 launch,
+    // round 4.  The barrier keeps the scheduler from moving them back up.)
+    __builtin_amdgcn_sched_barrier(0);
+    (void)nsamp;
+    const StreamParam *p = a.param + s;
+    const u32 perm2 = p->perm2;
+    // Stereo, nothing but the VU window asked for, and the stream's map the identity or the swap:
+    // the samples stay where they are and the two halves of a dword change roles instead (sw = 1:
+    // the low half is output channel 1) -- one v_perm_b32 per dword less.  A map that repeats a
+    // channel, and every run that writes PCM or floats, permutes as before.
+    constexpr bool ROLES = C == 2 && DO_VU && !WRITE_PCM && !WRITE_F32;
+    const bool keep = ROLES && (perm2 == 0x03020100u || perm2 == 0x01000302u);
+    const u32 sw = keep && perm2 == 0x01000302u ? 1u : 0u;
+    // Gains of the two dword halves: integer part and fraction (StreamParam).  Both channels' constants are
+    // loaded at FIXED offsets and the roles picked with scalar selects: indexed by `sw` the compiler forms
+    // s_load_dword with a register offset AND an immediate one, and on gfx950 (ROCm 7.2) that load came back
+    // from base + immediate alone -- both halves got channel 0's fraction (round 4, NOTES_r04).
+    const u32 mi01 = p->mi01;                                           // mi[0] | mi[1] << 16
+    const u32 mf0 = p->mf[0], mf1 = p->mf[C - 1];
+    const u32 mipk = C == 1 ? (mi01 & 0xffffu) * 0x10001u : (sw ? (mi01 >> 16) | (mi01 << 16) : mi01);
+    const u32 mflo = sw ? mf1 : mf0, mfhi = sw ? mf0 : mf1;
+    // StreamParam::mode: the general form serves every stream; the shorter ones are taken where the
+    // VALU binds (a VU window, no PCM result, whole tiles).  The branch comes after the loads are out.
+    constexpr bool MODES = DO_VU && !WRITE_PCM && FULL;
+    const u32 mode = MODES ? uniform(p->mode) : GAIN_GENERAL;
 
     if constexpr (ROLES) {
         if (!keep) {                             // (uniform: a wave works on one stream)
@@ -126,9 +146,9 @@ __device__ __forceinline__ void fast_tile(const RunArgs &a, u32 s, u32 k, u32 ns
             if constexpr (MODE == GAIN_IDENTITY)
                 qw[u][i] = gain2_identity(x[u][i], o[i]);
             else if constexpr (MODE == GAIN_BELOW_SCALE)
-                qw[u][i] = gain2_below(x[u][i], klo, khi, o[i]);
+                qw[u][i] = gain2_below(x[u][i], mflo, mfhi, o[i]);
             else
-                qw[u][i] = gain2(x[u][i], g2lo, g2hi, magic, shift, o[i]);
+                qw[u][i] = gain2<true>(x[u][i], mipk, mflo, mfhi, o[i]);
             if constexpr (DO_VU) {
                 vmax = pk_max(vmax, qw[u][i]);
                 pw[0].add_lo(qw[u][i]);
@@ -280,6 +300,13 @@ __device__ __forceinline__ void run_fast(const RunArgs &a)
     constexpr u32 TILE_VEC = 64 * U;
     static_assert(NW == 1 || !WRITE_F32, "the float-plane forms stage through LDS with one-wave barriers");
     const u32 lane = threadIdx.x & 63u;
+    // Every kernel argument a tile's loads need is read HERE, with the first batch of scalar loads: fetched where
+    // they are used they come behind two more waits -- and a scalar wait is a wait for everything issued so far.
+    // (No asm volatile to pin them: it makes every later load of the kernel a vector load.)
+    const int16_t *a_in = a.in;
+    int16_t *a_out = a.out;
+    const u64 a_stride = a.stride;
+    const u32 a_frames = a.frames;
     u32 s, k;
     if constexpr (NW == 1) {
         s = blockIdx.x / a.chunks;               // stream
@@ -301,7 +328,7 @@ __device__ __forceinline__ void run_fast(const RunArgs &a)
         __syncthreads();                         // (the only barrier: all waves are at their start)
     }
 
-    const u32 nfr = a.nframes ? a.nframes[s] : a.frames;
+    const u32 nfr = a.nframes ? a.nframes[s] : a_frames;
     const u32 nsamp = nfr * (u32)C;
     const u32 nfull = nsamp >> 3;                // whole 16-byte vectors
     const u32 ntail = nsamp & 7u;                // samples in the partial last vector
@@ -309,19 +336,15 @@ __device__ __forceinline__ void run_fast(const RunArgs &a)
 
     VuState *vs = DO_VU ? a.vu + s : nullptr;
     u64 base = 0;
-    if constexpr (DO_VU) {
-        // window position: read from one slot, the stream's first tile writes the other
-        base = vs->samples[a.parity];
-        if (k == 0 && lane == 0)
-            vs->samples[a.parity ^ 1u] = base + nsamp;
-    }
+    if constexpr (DO_VU)
+        base = window_base(a, vs, k, nsamp);
     if (v0 >= nfull + (ntail ? 1u : 0u)) {
         if constexpr (NW == 1)
             return;
     } else if (v0 + TILE_VEC <= nfull) {
-        fast_tile<C, WRITE_PCM, WRITE_F32, DO_VU, U, true>(a, s, k, nsamp, nfull, ntail, base, vs, share);
+        fast_tile<C, WRITE_PCM, WRITE_F32, DO_VU, U, true>(a, s, k, nsamp, nfull, ntail, base, vs, share, a_in, a_out, a_stride);
     } else {
-        fast_tile<C, WRITE_PCM, WRITE_F32, DO_VU, U, false>(a, s, k, nsamp, nfull, ntail, base, vs, share);
+        fast_tile<C, WRITE_PCM, WRITE_F32, DO_VU, U, false>(a, s, k, nsamp, nfull, ntail, base, vs, share, a_in, a_out, a_stride);
     }
     if constexpr (NW > 1 && DO_VU) {
         // LDS serves a wave's operations in order, and the waves' one after the other: the wave that counts
@@ -413,12 +436,14 @@ __global__ __launch_bounds__(64) void k_run_wide(RunArgs a)
     }
 
     const StreamParam *p = a.param + s;
-    const u32 magic = p->magic, shift = p->shift;
     const u32 cls = C == 16 ? (lane & 1u) : 0u;  // v0 and 64*u are even: vector parity = lane parity
-    u32 g2[NS];
+    u32 mipk[NG], mf[NS];                        // (per lane class for 16 channels: not uniform)
 #pragma unroll
     for (u32 i = 0; i < NS; i++)
-        g2[i] = p->gain2[i + 8u * cls];
+        mf[i] = p->mf[i + 8u * cls];
+#pragma unroll
+    for (u32 g = 0; g < NG; g++)
+        mipk[g] = (u32)p->mi[2u * g + 8u * cls] | ((u32)p->mi[2u * g + 1u + 8u * cls] << 16);
 
     const int16_t *ins = a.in + (u64)s * a.stride;
     const u32x4 *src = reinterpret_cast<const u32x4 *>(ins);
@@ -471,7 +496,7 @@ __global__ __launch_bounds__(64) void k_run_wide(RunArgs a)
             if constexpr (IDENT)
                 qw[u][i] = gain2_identity(x[u][i], o[i]);
             else
-                qw[u][i] = gain2(x[u][i], g2[2 * g], g2[2 * g + 1], magic, shift, o[i]);
+                qw[u][i] = gain2<C != 16>(x[u][i], mipk[g], mf[2 * g], mf[2 * g + 1], o[i]);
             if constexpr (DO_VU) {
                 vmax[g] = pk_max(vmax[g], qw[u][i]);
                 pw[2 * g].add_lo(qw[u][i]);
@@ -667,27 +692,27 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
     }
 
     const StreamParam *p = a.param + s;
-    const u32 magic = p->magic, shift = p->shift;
     const bool active = lane < W;
     const u32 lane_fr = 8u * lane / C;           // whole frames before this lane's vector in a row
     const u32 phase = 8u * lane - lane_fr * C;   // channel of its position 0
     const u32 FW = 8u * W / C;                   // frames per row (8W is a multiple of C)
-    // The shorter forms of the gain (GainShort, chosen per stream by the host) where the VALU counts
+    // The shorter forms of the gain (StreamParam::mode, chosen per stream by the host) where the VALU counts
     // most: a VU window and nothing written.  The branch is uniform: a wave works on one stream.
     constexpr bool MODES = DO_VU && !WRITE_PCM && !WRITE_F32;
-    const GainShort *gs = a.gshort + (MODES ? s : 0u);
-    const u32 mode = MODES ? uniform(gs->mode) : GAIN_GENERAL;
-    u32 ch[8], df[8], g2[8], km[8];
+    const u32 mode = MODES ? uniform(p->mode) : GAIN_GENERAL;
+    u32 ch[8], df[8], mipk[4], mf[8];
     u32 so[8];                                   // MAP: byte offset of position j's source in its row
 #pragma unroll
     for (u32 j = 0; j < 8; j++) {
         const u32 t = phase + j;
         df[j] = t / C;
         ch[j] = t - df[j] * C;
-        g2[j] = p->gain2[ch[j]];
-        km[j] = MODES ? gs->kmul[ch[j]] : 0u;
+        mf[j] = p->mf[ch[j]];
         so[j] = MAP ? 2u * ((lane_fr + df[j]) * C + p->chmap[ch[j]]) : 0u;
     }
+#pragma unroll
+    for (u32 i = 0; i < 4; i++)
+        mipk[i] = (u32)p->mi[ch[2 * i]] | ((u32)p->mi[ch[2 * i + 1]] << 16);
 
     const int16_t *ins = a.in + (u64)s * a.stride;
     const u32x4 *src = reinterpret_cast<const u32x4 *>(ins);
@@ -720,9 +745,9 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
                 if constexpr (MODE == GAIN_IDENTITY)
                     q[u] = gain2_identity(x[u][i], oc[u]);
                 else if constexpr (MODE == GAIN_BELOW_SCALE)
-                    q[u] = gain2_below(x[u][i], km[2 * i], km[2 * i + 1], oc[u]);
+                    q[u] = gain2_below(x[u][i], mf[2 * i], mf[2 * i + 1], oc[u]);
                 else
-                    q[u] = gain2(x[u][i], g2[2 * i], g2[2 * i + 1], magic, shift, oc[u]);
+                    q[u] = gain2<false>(x[u][i], mipk[i], mf[2 * i], mf[2 * i + 1], oc[u]);
                 o[u][i] = oc[u];
             }
             if constexpr (DO_VU)

@@ -220,7 +220,7 @@ void k_eq_pipe(EqArgs a)
     const u32 l_s = min(l_stream, a.streams - 1);
     const bool l_live = is_tin && l_stream < a.streams;
     const u32 l_sidx = l_s * C + l_ch;
-    u32 l_magic = 0, l_shift = 0, l_g2 = 0, l_n = 0, l_m = 0;
+    u32 l_mi = 0, l_mf = 0, l_n = 0, l_m = 0;                // (gain: integer part and fraction, StreamParam)
     // feed-forward registers: b0 b1 b2 and x[t-1], x[t-2] before the next block.  A T-in lane
     // uses [0][0] for section 0 of its row; a T-ff lane [p][k] for section k of the row of pass p.
     float fc[PASSES][NSEC][3];
@@ -233,9 +233,8 @@ void k_eq_pipe(EqArgs a)
             sx1[p][k] = sx2[p][k] = 0.f;
         }
     if (is_tin) {
-        l_magic = a.param[l_s].magic;
-        l_shift = a.param[l_s].shift;
-        l_g2 = a.param[l_s].gain2[l_ch];
+        l_mi = a.param[l_s].mi[l_ch];
+        l_mf = a.param[l_s].mf[l_ch];
         l_m = MONO ? 0u : a.param[l_s].chmap[l_ch];       // the input channel this row reads
         l_n = nfr_lds[l_r];
         if (l_live) {
@@ -280,8 +279,8 @@ void k_eq_pipe(EqArgs a)
         }
     }
 
-    // gain disabled (scale 0, or every gain equal to the scale) is stored as 1/1: x -> x
-    const bool gain_off = __all(l_g2 == 2u && l_shift == 0u);
+    // gain disabled (scale 0, or every gain equal to the scale) is stored as integer part 1, fraction 0: x -> x
+    const bool gain_off = __all(l_mi == 1u && l_mf == 0u);
 
     // The T waves keep two blocks of PCM in flight: a block's HBM latency is hidden behind
     // two pipeline steps.  The load is unconditional (address clamped into the stream's own
@@ -324,7 +323,7 @@ void k_eq_pipe(EqArgs a)
         auto gain_one = [&](const u32 frame) -> float {
             const int xs = (int)l_src[MONO ? frame : frame * C + l_m];
             const u32 ax = (u32)(xs < 0 ? -xs : xs);
-            const u32 qq = __umulhi(__umul24(ax, l_g2), l_magic) >> l_shift;
+            const u32 qq = __umul24(ax, l_mi) + __umulhi(ax, l_mf);
             const float m = fminf((float)qq, xs < 0 ? 32768.0f : 32767.0f);
             return (xs < 0 ? -m : m) * (1.0f / 32768.0f);
         };
@@ -491,10 +490,9 @@ void k_eq_pipe(EqArgs a)
                     for (u32 q = 0; q < 4; q++) {
                         const u32 sg = pk_sign(w[q]);
                         const u32 aw = pk_sub(w[q] ^ sg, sg);
-                        const u32 n0 = __umul24(aw & 0xffffu, l_g2);
-                        const u32 n1 = __umul24(aw >> 16, l_g2);
-                        const float m0 = (float)(__umulhi(n0, l_magic) >> l_shift);
-                        const float m1 = (float)(__umulhi(n1, l_magic) >> l_shift);
+                        const u32 x0 = aw & 0xffffu, x1 = aw >> 16;
+                        const float m0 = (float)(__umul24(x0, l_mi) + __umulhi(x0, l_mf));
+                        const float m1 = (float)(__umul24(x1, l_mi) + __umulhi(x1, l_mf));
                         const u32 b0 = (__builtin_bit_cast(u32, m0) & 0x7fffffffu) | ((w[q] << 16) & 0x80000000u);
                         const u32 b1 = (__builtin_bit_cast(u32, m1) & 0x7fffffffu) | (w[q] & 0x80000000u);
                         x[2 * q] = __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, b0), -32768.0f, 32767.0f);

@@ -233,21 +233,39 @@ def test_product_fails_loudly_without_gpu(cm):
 
 
 def test_division_constants_are_exact(cm):
-    """q = mulhi(2n, magic) >> shift equals n // scale for all scales and adversarial n
-    (n = |x|*gain < 2^31).  The GPU test repeats a subset on the device."""
+    """floor(|x| * gain / scale) == |x| * mi + ((|x| * mf) >> 32) for every magnitude 0..32768 -- the two
+    instructions the kernels spend per sample (v_mul_hi_u32, v_mad_u32_u24; StreamParam in cmhip_internal.h),
+    against the reference's 64-bit multiply and truncating divide (ref: src/transform.c:111-119).  Every class
+    of (gain, scale): gain below / equal to / a multiple of / just beside a multiple of the scale, scale 1,
+    powers of two and their neighbours, primes, the extremes 65535/1 and 1/65535, and random pairs.  The GPU
+    test test_every_scale_divides_exactly_on_device repeats a subset on the device."""
     rng = np.random.default_rng(3)
-    nmax = 32768 * 65535
-    for scale in list(range(1, 2050)) + [4095, 4096, 4097, 21845, 32767, 32768, 32769, 43691,
-                                          65521, 65534, 65535] + [int(v) for v in rng.integers(1, 65536, 300)]:
-        m, sh = cm.magic(scale)
-        assert m < 2 ** 32 and sh <= 16
-        ks = np.arange(0, nmax // scale + 2, max(1, (nmax // scale) // 257), dtype=np.uint64)
-        n = np.concatenate([ks * np.uint64(scale), ks * np.uint64(scale) + np.uint64(scale - 1),
-                            rng.integers(0, nmax + 1, 2000).astype(np.uint64),
-                            np.array([0, 1, nmax, nmax - 1], dtype=np.uint64)])
-        n = n[n <= nmax]
-        q = ((n * np.uint64(2) * np.uint64(m)) >> np.uint64(32)) >> np.uint64(sh)
-        assert np.array_equal(q, n // np.uint64(scale)), scale
+    x = np.arange(0, 32769, dtype=np.uint64)
+    scales = list(range(1, 260)) + [511, 512, 513, 999, 1000, 1001, 4095, 4096, 4097, 21845, 32767, 32768, 32769,
+                                    43691, 65521, 65534, 65535] + [int(v) for v in rng.integers(1, 65536, 120)]
+    checked = 0
+    for scale in scales:
+        gains = {1, 2, scale, 65535, 65534, 32768, 32767, max(1, scale - 1), min(65535, scale + 1),
+                 max(1, scale // 2), max(1, scale // 3)}
+        for k in (2, 3, 7, 64, 65535 // scale):
+            for d in (-1, 0, 1):
+                g = k * scale + d
+                if 1 <= g <= 65535:
+                    gains.add(g)
+        gains.update(int(v) for v in rng.integers(1, 65536, 6))
+        for gain in sorted(gains):
+            mi, mf = cm.gain_consts(gain, scale)
+            assert mi == gain // scale and mf < 2 ** 32
+            assert (mf == 0) == (gain % scale == 0)
+            q = x * np.uint64(mi) + ((x * np.uint64(mf)) >> np.uint64(32))
+            assert np.array_equal(q, x * np.uint64(gain) // np.uint64(scale)), (gain, scale)
+            checked += 1
+    assert checked > 5000
+    # the short form of the read-only runs is the mi == 0 case: nothing but the mulhi
+    for gain, scale in ((900, 1000), (1, 65535), (65534, 65535), (1, 2), (32767, 32768)):
+        mi, mf = cm.gain_consts(gain, scale)
+        assert mi == 0
+        assert np.array_equal((x * np.uint64(mf)) >> np.uint64(32), x * np.uint64(gain) // np.uint64(scale))
 
 
 def test_logging_format(cm):
