@@ -7,6 +7,10 @@
 #include <stdint.h>
 #include <sys/types.h>
 
+/* (first: inside the reference's build libigloo's headers want the application's types declared before
+ * anything else pulls <igloo/ro.h> in) */
+#include "ro_glue.h"
+
 #include <coolmic-dsp/coolmic-dsp.h>
 #include <coolmic-dsp/iohandle.h>
 #include <coolmic-dsp/logging.h>

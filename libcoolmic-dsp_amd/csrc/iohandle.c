@@ -3,7 +3,7 @@
 #include "host_internal.h"
 
 struct coolmic_iohandle {
-    coolmic_ro_base_t base;
+    igloo_ro_base_t __base;
     void *userdata;
     int (*free_fn)(void *userdata);
     ssize_t (*read_fn)(void *userdata, void *buffer, size_t len);
@@ -17,9 +17,7 @@ static void iohandle_destroy(void *self)
         h->free_fn(h->userdata);             /* backend cleanup, once */
 }
 
-static const coolmic_ro_type_t iohandle_type = {
-    "coolmic_iohandle_t", sizeof(coolmic_iohandle_t), iohandle_destroy
-};
+COOLMIC_RO_TYPE(coolmic_iohandle_t, iohandle_destroy);
 
 coolmic_iohandle_t *coolmic_iohandle_new(const char *name, igloo_ro_t associated, void *userdata,
                                          int (*free)(void *), ssize_t (*read)(void *, void *, size_t),
@@ -29,7 +27,7 @@ coolmic_iohandle_t *coolmic_iohandle_new(const char *name, igloo_ro_t associated
 
     if (read == NULL)                        /* a handle nobody can read is refused */
         return NULL;
-    h = coolmic_ro_new_raw(&iohandle_type, name, associated);
+    h = COOLMIC_RO_NEW(coolmic_iohandle_t, name, associated);
     if (h == NULL)
         return NULL;
     h->userdata = userdata;

@@ -15,7 +15,7 @@
 enum source_kind { SOURCE_NULL, SOURCE_SINE, SOURCE_STDIO };
 
 struct coolmic_snddev {
-    coolmic_ro_base_t base;
+    igloo_ro_base_t __base;
     enum source_kind kind;
     /* sine: one period and the byte position inside it */
     int16_t period[96];
@@ -37,7 +37,7 @@ static void snddev_destroy(void *self)
         fclose(dev->file);
 }
 
-static const coolmic_ro_type_t snddev_type = {"coolmic_snddev_t", sizeof(coolmic_snddev_t), snddev_destroy};
+COOLMIC_RO_TYPE(coolmic_snddev_t, snddev_destroy);
 
 static ssize_t snddev_read(void *userdata, void *buffer, size_t len)
 {
@@ -112,7 +112,7 @@ coolmic_snddev_t *coolmic_snddev_new(const char *name, igloo_ro_t associated, co
         return NULL;
     }
 
-    dev = coolmic_ro_new_raw(&snddev_type, name, associated);
+    dev = COOLMIC_RO_NEW(coolmic_snddev_t, name, associated);
     if (dev == NULL) {
         if (file != NULL)
             fclose(file);

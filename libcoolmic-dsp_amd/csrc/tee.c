@@ -10,7 +10,7 @@
 #define TEE_BUFFER_MAX 8192
 
 struct coolmic_tee {
-    coolmic_ro_base_t base;
+    igloo_ro_base_t __base;
     coolmic_iohandle_t *in;
     size_t readers;
     ssize_t next_reader;
@@ -40,7 +40,7 @@ static void tee_destroy(void *self)
     free(t->buffer);
 }
 
-static const coolmic_ro_type_t tee_type = {"coolmic_tee_t", sizeof(coolmic_tee_t), tee_destroy};
+COOLMIC_RO_TYPE(coolmic_tee_t, tee_destroy);
 
 coolmic_tee_t *coolmic_tee_new(const char *name, igloo_ro_t associated, size_t readers)
 {
@@ -48,7 +48,7 @@ coolmic_tee_t *coolmic_tee_new(const char *name, igloo_ro_t associated, size_t r
 
     if (readers < 1 || readers > COOLMIC_DSP_TEE_MAX_READERS)
         return NULL;
-    t = coolmic_ro_new_raw(&tee_type, name, associated);
+    t = COOLMIC_RO_NEW(coolmic_tee_t, name, associated);
     if (t != NULL)
         t->readers = readers;
     return t;

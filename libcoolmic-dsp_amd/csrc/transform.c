@@ -37,7 +37,7 @@ typedef struct {
 } transform_record_t;
 
 struct coolmic_transform {
-    coolmic_ro_base_t base;
+    igloo_ro_base_t __base;
     coolmic_iohandle_t *io;
     unsigned char carry[2 * COOLMIC_DSP_TRANSFORM_MAX_CHANNELS - 1];
     size_t carry_fill;
@@ -88,9 +88,7 @@ static void transform_destroy(void *self)
     pthread_mutex_destroy(&t->lock);
 }
 
-static const coolmic_ro_type_t transform_type = {
-    "coolmic_transform_t", sizeof(coolmic_transform_t), transform_destroy
-};
+COOLMIC_RO_TYPE(coolmic_transform_t, transform_destroy);
 
 coolmic_transform_t *coolmic_transform_new(const char *name, igloo_ro_t associated,
                                            uint_least32_t rate, unsigned int channels)
@@ -100,7 +98,7 @@ coolmic_transform_t *coolmic_transform_new(const char *name, igloo_ro_t associat
 
     if (!rate || !channels || channels > COOLMIC_DSP_TRANSFORM_MAX_CHANNELS)
         return NULL;
-    t = coolmic_ro_new_raw(&transform_type, name, associated);
+    t = COOLMIC_RO_NEW(coolmic_transform_t, name, associated);
     if (t == NULL)
         return NULL;
     pthread_mutex_init(&t->lock, NULL);
@@ -370,7 +368,7 @@ static int transform_handle_eof(void *userdata)
 
 static int transform_handle_free(void *userdata)
 {
-    return coolmic_ro_unref(userdata);
+    return coolmic_ro_unref((coolmic_transform_t *)userdata);
 }
 
 /* ---- the fused VU window (internal: vumeter.c; declared in host_internal.h) ------------------ */

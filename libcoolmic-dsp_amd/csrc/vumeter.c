@@ -41,7 +41,7 @@
 enum { METER_OWN = 0, METER_DIRECT = 1, METER_RECORDS = 2 };
 
 struct coolmic_vumeter {
-    coolmic_ro_base_t base;
+    igloo_ro_base_t __base;
     coolmic_iohandle_t *in;
     uint_least32_t rate;
     unsigned int channels;
@@ -87,9 +87,7 @@ static void vumeter_destroy(void *self)
     free(v->held);
 }
 
-static const coolmic_ro_type_t vumeter_type = {
-    "coolmic_vumeter_t", sizeof(coolmic_vumeter_t), vumeter_destroy
-};
+COOLMIC_RO_TYPE(coolmic_vumeter_t, vumeter_destroy);
 
 coolmic_vumeter_t *coolmic_vumeter_new(const char *name, igloo_ro_t associated,
                                        uint_least32_t rate, unsigned int channels)
@@ -98,7 +96,7 @@ coolmic_vumeter_t *coolmic_vumeter_new(const char *name, igloo_ro_t associated,
 
     if (!rate || !channels || channels > COOLMIC_DSP_VUMETER_MAX_CHANNELS)
         return NULL;
-    v = coolmic_ro_new_raw(&vumeter_type, name, associated);
+    v = COOLMIC_RO_NEW(coolmic_vumeter_t, name, associated);
     if (v == NULL)
         return NULL;
     v->rate = rate;

@@ -145,6 +145,76 @@ def test_dropin_build_exports_what_the_replaced_units_define():
     assert not sorted(declared - full)
 
 
+def _igloo_uses(text):
+    """igloo identifiers of a C text -> {name: set of argument counts} (None: used without a call).  Comments
+    and string literals are dropped first; arguments are counted at the top nesting level."""
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r'"(\\.|[^"\\])*"', '""', text)
+    uses = {}
+    for m in re.finditer(r"\bigloo_\w+", text):
+        name, i = m.group(0), m.end()
+        while i < len(text) and text[i] in " \t\\\n":
+            i += 1
+        arity = None
+        if i < len(text) and text[i] == "(":
+            depth, args, seen, j = 0, 0, False, i
+            while j < len(text):
+                c = text[j]
+                if c in "([{":
+                    depth += 1
+                elif c in ")]}":
+                    depth -= 1
+                    if depth == 0:
+                        break
+                elif c == "," and depth == 1:
+                    args += 1
+                elif depth == 1 and not c.isspace():
+                    seen = True
+                j += 1
+            arity = args + 1 if seen else 0
+        uses.setdefault(name, set()).add(arity)
+    return uses
+
+
+def test_igloo_glue_uses_the_references_igloo_surface():
+    """`make dropin IGLOO=1` turns the stages into libigloo objects through csrc/ro_igloo.h.
+    libigloo is not in this image, so the file cannot be compiled here; what can be held to account is that
+    every igloo_* identifier it uses is one the reference's own sources use, called with the same number of
+    arguments (ref: src/transform.c:54-62,72; src/vumeter.c:59-67,76; src/iohandle.c:41-52,62; src/tee.c:71-81,227)
+    -- and that the default build never sees the file."""
+    csrc = os.path.join(ROOT, "libcoolmic-dsp_amd", "csrc")
+    glue = open(os.path.join(csrc, "ro_igloo.h")).read()
+    own = _igloo_uses(glue)
+    assert {"igloo_RO_PUBLIC_TYPE", "igloo_RO_TYPEDECL_FREE", "igloo_RO_TO_TYPE", "igloo_ro_new_raw", "igloo_ro_ref",
+            "igloo_ro_unref", "igloo_ro_t"} <= set(own), sorted(own)
+    # out of the default build: ro_glue.h takes it under the switch only, it refuses to compile without it, and
+    # the Makefile leaves csrc/ro.c out exactly when IGLOO is set
+    assert re.search(r"#ifdef COOLMIC_DSP_USE_LIBIGLOO\s*\n#include \"ro_igloo.h\"\s*\n#else", open(os.path.join(csrc, "ro_glue.h")).read())
+    assert "#error" in glue
+    mk = open(os.path.join(ROOT, "libcoolmic-dsp_amd", "Makefile")).read()
+    assert re.search(r"ifdef IGLOO\n(?:.*\n)*?DROPIN_C\s*:=\s*\$\(filter-out ro\.c,\$\(DROPIN_C\)\)", mk)
+    assert "-DCOOLMIC_DSP_USE_LIBIGLOO" in mk and "COOLMIC_DSP_USE_LIBIGLOO" not in mk.split("ifdef IGLOO")[0]
+    # the stages themselves speak only the glue's vocabulary: no libigloo name of their own beyond the two
+    # the public ro-compat.h supplies in both builds
+    for unit in ("iohandle.c", "transform.c", "vumeter.c", "tee.c"):
+        names = set(_igloo_uses(open(os.path.join(csrc, unit)).read()))
+        assert names <= {"igloo_ro_t", "igloo_ro_base_t", "igloo_RO_NULL"}, (unit, names)
+    if not os.path.isdir(os.path.join(REFERENCE, "src")):
+        pytest.skip("the reference's sources are not on this machine; the glue was checked without them")
+    ref = {}
+    for d in ("src", os.path.join("include", "coolmic-dsp")):
+        for f in sorted(os.listdir(os.path.join(REFERENCE, d))):
+            if f.endswith((".c", ".h")):
+                for name, ar in _igloo_uses(open(os.path.join(REFERENCE, d, f), errors="replace").read()).items():
+                    ref.setdefault(name, set()).update(ar)
+    unknown = sorted(set(own) - set(ref))
+    assert not unknown, "igloo names the reference never uses: %s" % unknown
+    wrong = {n: (sorted(a, key=str), sorted(ref[n], key=str)) for n, a in own.items() if not a <= ref[n]}
+    assert not wrong, "argument counts differ from the reference's usage: %s" % wrong
+    # and the one private header it includes is the reference's own
+    assert os.path.exists(os.path.join(REFERENCE, "src", "types_private.h"))
+
+
 def test_host_feature_tokens_of_the_dropin_build():
     """inside the reference's build coolmic_features() lists the HOST's encoders and drivers (handed in by its
     Makefile) plus the token of this path (ref: src/coolmic-dsp.c:64-83)"""

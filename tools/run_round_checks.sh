@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-end checks on the GPU box (one gpurun call): GPU tests, smoke, the default bench line, rocprofv3 kernel
-# stats of configs 2 and 3 and of the six-channel workload x6, HBM counters of the three (tools/hbm_pmc.sh), the
+# stats of configs 2 and 3, of the read-only leg c2ro in its three gain forms and of the six-channel workload x6,
+# HBM counters of them (tools/hbm_pmc.sh), the
 # N = 1 lines of the other workloads, the two-rank rehearsal, the tables DESIGN.md quotes.  Everything lands
 # under gpurun_out/; tools/collect_profiles.sh copies what is kept into profiles/.
 set -e
@@ -12,24 +13,30 @@ timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()"
 timeout -k 10 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 cat gpurun_out/bench_default.json
 cd /tmp && export TMPDIR=/tmp
-prof() {    # name, environment assignment, bench arguments...
-    local name=$1 envs=$2; shift 2
+prof() {    # name, bench arguments...
+    local name=$1; shift
     rm -rf $R/gpurun_out/prof_$name
-    env $envs timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$name -- \
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$name -- \
         python3 $R/bench.py "$@" --steps 100 --warmup 100 --no-cpu --no-extras > $R/gpurun_out/${name}_rocprof.json 2> $R/gpurun_out/${name}_rocprof.err
     cat $R/gpurun_out/${name}_rocprof.json
 }
-# the batch's arrays where hipMalloc first puts them: every launch of the kernel in the trace is a step of the bench
-prof c2 COOLMIC_BENCH_PLACE=0
-# with the engine's placement search, as the default line runs: the trace also holds the search's probe launches
-# and the place-off leg's (setup.placement.probe_launches and 64 + warm-up in the line say how many)
-prof c2_search COOLMIC_BENCH_PLACE=1
-prof c3 COOLMIC_BENCH_PLACE=0 --workload c3
-prof x6 COOLMIC_BENCH_PLACE=0 --workload x6
+# (--no-extras: every launch of the kernel in a trace is a step of the bench; the batch's arrays lie where hipMalloc
+# first puts them -- the library's default, and what the default line's `value` and `roofline` are measured on)
+prof c2
+# the north star's literal leg: VU only, 2 B read per sample, the three arithmetic forms of k_run_fast_ro
+prof c2ro --workload c2ro
+prof c2ro_below --workload c2ro --gain below
+prof c2ro_off --workload c2ro --gain off
+prof c3 --workload c3
+prof x6 --workload x6
 cd $R
-for w in c2 c3 x6; do
+for w in c2 c2ro c3 x6; do
     timeout -k 10 300 bash tools/hbm_pmc.sh $w > gpurun_out/hbm_$w.log 2>&1 && tail -8 gpurun_out/hbm_$w.log
 done
+for g in below off; do
+    timeout -k 10 300 bash tools/hbm_pmc.sh c2ro $g > gpurun_out/hbm_c2ro_$g.log 2>&1 && tail -8 gpurun_out/hbm_c2ro_$g.log
+done
+timeout -k 10 300 python bench.py --workload c2ro --no-cpu > gpurun_out/n1_c2ro.json 2> gpurun_out/n1_c2ro.err
 timeout -k 10 300 python bench.py --workload c4 --no-extras --no-cpu > gpurun_out/n1_c4.json 2> gpurun_out/n1_c4.err
 timeout -k 10 300 env COOLMIC_BENCH_FORCE_NODE=1 python bench.py --workload c5 --no-extras --no-cpu > gpurun_out/n1_c5.json 2> gpurun_out/n1_c5.err
 timeout -k 10 300 python bench.py --workload c3 --no-cpu > gpurun_out/n1_c3.json 2> gpurun_out/n1_c3.err
