@@ -45,6 +45,20 @@ coolmic_group_t    *coolmic_group_new(const char *name, igloo_ro_t associated, u
                                       unsigned int channels, unsigned int max_streams,
                                       size_t block_frames, unsigned int queue_blocks);
 
+/* The same group on a GPU of the caller's choice instead of $COOLMIC_HIP_DEVICE (default 0): a host that drives
+ * every GPU of a node from one process makes one group per GPU and gives capture stream s to the group of GPU
+ * s % N, one pump thread per group (examples/group_server.c --gpus N).  NULL also for a device the
+ * process does not see. */
+coolmic_group_t    *coolmic_group_new_on(int device, const char *name, igloo_ro_t associated, uint_least32_t rate,
+                                         unsigned int channels, unsigned int max_streams,
+                                         size_t block_frames, unsigned int queue_blocks);
+/* the GPU a group lives on; -1 for NULL */
+int                 coolmic_group_device(coolmic_group_t *self);
+/* the group's batch engine (cmhip_batch_t of <coolmic_hip.h>), for what the group itself does not wrap: the
+ * node-global VU over the groups of several GPUs (cmhip_node_partial(node, engine, ...) after a pump; the record
+ * counts the block that pump put in flight).  Owned by the group; not to be run, resized or freed. */
+struct cmhip_batch *coolmic_group_engine(coolmic_group_t *self);
+
 /* adds a stream fed by `source` (takes its own reference); returns the slot (>= 0) or
  * COOLMIC_ERROR_FAULT / COOLMIC_ERROR_BUSY when the group is full */
 int                 coolmic_group_add_stream(coolmic_group_t *self, coolmic_iohandle_t *source);

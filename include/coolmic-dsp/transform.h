@@ -63,6 +63,12 @@ int                    coolmic_transform_set_channel_map(coolmic_transform_t *se
 int                    coolmic_transform_set_eq(coolmic_transform_t *self, unsigned int sections,
                                                 const float *coef);
 
+/* Which GPU this transform's arithmetic runs on (one process may drive every GPU of a node: one pipeline per
+ * capture stream, ref: src/simple.c:198-200, stream s on GPU s % N).  Valid until the first read that needs
+ * arithmetic has created the transform's device state: COOLMIC_ERROR_BUSY after that, COOLMIC_ERROR_INVAL for a
+ * device the process does not see.  Without a call: $COOLMIC_HIP_DEVICE, else 0. */
+int                    coolmic_transform_set_device(coolmic_transform_t *self, int device);
+
 #ifdef __cplusplus
 }
 #endif

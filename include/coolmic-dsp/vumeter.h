@@ -48,6 +48,14 @@ ssize_t             coolmic_vumeter_read(coolmic_vumeter_t *self, ssize_t maxlen
 int                 coolmic_vumeter_result(coolmic_vumeter_t *self,
                                            coolmic_vumeter_result_t *result);
 
+/* ---- addition of this implementation (not in the reference) ---- */
+
+/* Which GPU a meter with a launch of its own accounts its frames on (a meter that shares the launch of the
+ * transform above it uses that transform's, coolmic_transform_set_device()).  COOLMIC_ERROR_BUSY once the meter
+ * has device state of its own, COOLMIC_ERROR_INVAL for a device the process does not see.  Without a call:
+ * $COOLMIC_HIP_DEVICE, else 0. */
+int                 coolmic_vumeter_set_device(coolmic_vumeter_t *self, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,8 +140,11 @@ int cmhip_batch_download(cmhip_batch_t *b, unsigned int stream, int16_t *pcm, si
 int   cmhip_batch_upload_all(cmhip_batch_t *b, const int16_t *host, size_t frames);
 int   cmhip_batch_download_all(cmhip_batch_t *b, int16_t *host, size_t frames);
 void *cmhip_host_alloc(size_t bytes);             /* NULL on failure */
-/* pinned and mapped into the device: the host uses the returned pointer, kernels *device_ptr */
+/* pinned and mapped into the device: the host uses the returned pointer, kernels *device_ptr.
+ * (_on: the device whose kernels will use it -- a process that drives several GPUs; the plain form takes
+ * whichever device is current in the calling thread) */
 void *cmhip_host_alloc_mapped(size_t bytes, void **device_ptr);
+void *cmhip_host_alloc_mapped_on(int device, size_t bytes, void **device_ptr);
 void  cmhip_host_free(void *p);
 /* reads an input slot back (generated or uploaded PCM); synchronises */
 int cmhip_batch_download_input(cmhip_batch_t *b, unsigned int stream, int16_t *pcm, size_t frames);

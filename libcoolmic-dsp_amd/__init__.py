@@ -194,6 +194,12 @@ SIGNATURES = {
     "coolmic_util_vu_argb": (None, [_vp, C.c_size_t, C.c_char_p, _vp, _vp]),
     # include/coolmic-dsp/group.h
     "coolmic_group_new": (_vp, [C.c_char_p, _vp, C.c_uint32, C.c_uint, C.c_uint, C.c_size_t, C.c_uint]),
+    "coolmic_group_new_on": (_vp, [C.c_int, C.c_char_p, _vp, C.c_uint32, C.c_uint, C.c_uint, C.c_size_t, C.c_uint]),
+    "coolmic_group_device": (C.c_int, [_vp]),
+    "coolmic_group_engine": (_vp, [_vp]),
+    "coolmic_transform_set_device": (C.c_int, [_vp, C.c_int]),
+    "coolmic_vumeter_set_device": (C.c_int, [_vp, C.c_int]),
+    "cmhip_host_alloc_mapped_on": (_vp, [C.c_int, C.c_size_t, _P(_vp)]),
     "coolmic_group_add_stream": (C.c_int, [_vp, _vp]),
     "coolmic_group_set_master_gain": (C.c_int, [_vp, C.c_uint, C.c_uint, C.c_uint16, _P(C.c_uint16)]),
     "coolmic_group_set_channel_map": (C.c_int, [_vp, C.c_uint, _vp]),
@@ -204,7 +210,11 @@ SIGNATURES = {
     "coolmic_group_vumeter_result": (C.c_int, [_vp, C.c_uint, _P(VuResult)]),
     "coolmic_group_streams": (C.c_uint, [_vp]),
 }
+MISSING = []        # entry points this build of the library lacks (an older build under tools/ab_two_libs.py)
 for _name, (_res, _args) in SIGNATURES.items():
+    if not hasattr(lib, _name):
+        MISSING.append(_name)
+        continue
     _fn = getattr(lib, _name)
     _fn.restype = _res
     if _args is not None:
@@ -726,6 +736,9 @@ class Transform:
         m = np.asarray(cmap, dtype=np.uint8)
         return lib.coolmic_transform_set_channel_map(self.ptr, m.ctypes.data)
 
+    def set_device(self, device):
+        return lib.coolmic_transform_set_device(self.ptr, device)
+
     def set_eq(self, coef):
         """coef: 5 floats per section (b0 b1 b2 a1 a2), or None / empty to switch the filter off"""
         if coef is None or len(coef) == 0:
@@ -763,6 +776,9 @@ class Vumeter:
     def reset(self):
         return lib.coolmic_vumeter_reset(self.ptr)
 
+    def set_device(self, device):
+        return lib.coolmic_vumeter_set_device(self.ptr, device)
+
     def mode(self):
         """test hook: 0 own batch, 1 shares the launch of the transform right above, 2 shares it through a tee"""
         return lib.coolmic_debug_vumeter_mode(self.ptr)
@@ -794,12 +810,24 @@ class Tee:
 class Group:
     """coolmic_group_t: many transform -> vumeter pipelines, one launch per block"""
 
-    def __init__(self, channels, max_streams, block_frames, queue_blocks=2, rate=48000):
-        self.ptr = lib.coolmic_group_new(None, None, rate, channels, max_streams, block_frames,
-                                         queue_blocks)
+    def __init__(self, channels, max_streams, block_frames, queue_blocks=2, rate=48000, device=None):
+        if device is None:
+            self.ptr = lib.coolmic_group_new(None, None, rate, channels, max_streams, block_frames,
+                                             queue_blocks)
+        else:
+            self.ptr = lib.coolmic_group_new_on(device, None, None, rate, channels, max_streams, block_frames,
+                                                queue_blocks)
         if not self.ptr:
             raise CoolmicError("coolmic_group_new", ERROR_GENERIC)
         self.channels = channels
+
+    @property
+    def device(self):
+        return lib.coolmic_group_device(self.ptr)
+
+    def engine(self):
+        """the group's cmhip_batch_t (a borrowed pointer: cmhip_node_partial and friends)"""
+        return lib.coolmic_group_engine(self.ptr)
 
     def add_stream(self, handle):
         return lib.coolmic_group_add_stream(self.ptr, handle.ptr if handle else None)

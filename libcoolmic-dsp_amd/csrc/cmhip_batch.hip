@@ -1089,6 +1089,16 @@ extern "C" void *cmhip_host_alloc_mapped(size_t bytes, void **device_ptr)
     return p;
 }
 
+extern "C" void *cmhip_host_alloc_mapped_on(int device, size_t bytes, void **device_ptr)
+{
+    if (device < 0 || device >= cmhip_device_count() || hipSetDevice(device) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(COOLMIC_ERROR_INVAL, "cmhip_host_alloc_mapped_on: no HIP device %d", device);
+        return nullptr;
+    }
+    return cmhip_host_alloc_mapped(bytes, device_ptr);
+}
+
 extern "C" void cmhip_host_free(void *p)
 {
     if (p)

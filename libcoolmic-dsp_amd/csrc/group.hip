@@ -42,6 +42,7 @@ struct coolmic_group {
     unsigned int channels, max_streams, queue_blocks;
     size_t block_frames;
     cmhip_batch_t *batch;
+    int device;                              // the GPU the batch lives on (coolmic_group_new_on)
     int16_t *h_in[2];                        // input sets, host view
     void *d_in[2];                           // ... device view
     std::vector<int16_t *> *h_out;           // ring of output sets (queue_blocks + 2), host view
@@ -94,9 +95,27 @@ extern "C" coolmic_group_t *coolmic_group_new(const char *name, igloo_ro_t assoc
                                               unsigned int max_streams, size_t block_frames,
                                               unsigned int queue_blocks)
 {
+    return coolmic_group_new_on(coolmic_hip_default_device(), name, associated, rate, channels, max_streams,
+                                block_frames, queue_blocks);
+}
+
+extern "C" int coolmic_group_device(coolmic_group_t *self) { return self ? self->device : -1; }
+extern "C" struct cmhip_batch *coolmic_group_engine(coolmic_group_t *self) { return self ? self->batch : NULL; }
+
+extern "C" coolmic_group_t *coolmic_group_new_on(int device, const char *name, igloo_ro_t associated,
+                                                 uint_least32_t rate, unsigned int channels,
+                                                 unsigned int max_streams, size_t block_frames,
+                                                 unsigned int queue_blocks)
+{
     if (!rate || !channels || channels > COOLMIC_DSP_VUMETER_MAX_CHANNELS || !max_streams ||
         !block_frames)
         return NULL;
+    if (coolmic_hip_check_device(device) != COOLMIC_ERROR_NONE) {
+        coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_NOSYS,
+                            "no HIP device %d for the group (%d visible; there is no CPU path)", device,
+                            cmhip_device_count());
+        return NULL;
+    }
     coolmic_group_t *g = (coolmic_group_t *)coolmic_ro_new_raw(&group_type, name, associated);
     if (!g)
         return NULL;
@@ -105,10 +124,11 @@ extern "C" coolmic_group_t *coolmic_group_new(const char *name, igloo_ro_t assoc
     g->max_streams = max_streams;
     g->block_frames = block_frames;
     g->queue_blocks = queue_blocks ? queue_blocks : 1;
+    g->device = device;
 
     cmhip_batch_desc_t d;
     memset(&d, 0, sizeof(d));
-    d.device = coolmic_hip_default_device();
+    d.device = device;
     d.streams = max_streams;
     d.channels = channels;
     d.rate = (unsigned int)rate;
@@ -130,13 +150,13 @@ extern "C" coolmic_group_t *coolmic_group_new(const char *name, igloo_ro_t assoc
     g->out_users = new std::vector<unsigned int>(nout, 0);
     bool ok = true;
     for (int i = 0; i < 2 && ok; i++) {
-        g->h_in[i] = (int16_t *)cmhip_host_alloc_mapped(bytes, &g->d_in[i]);
+        g->h_in[i] = (int16_t *)cmhip_host_alloc_mapped_on(device, bytes, &g->d_in[i]);
         ok = g->h_in[i] != nullptr;
         if (ok)
             memset(g->h_in[i], 0, bytes);
     }
     for (unsigned i = 0; i < nout && ok; i++) {
-        (*g->h_out)[i] = (int16_t *)cmhip_host_alloc_mapped(bytes, &(*g->d_out)[i]);
+        (*g->h_out)[i] = (int16_t *)cmhip_host_alloc_mapped_on(device, bytes, &(*g->d_out)[i]);
         ok = (*g->h_out)[i] != nullptr;
     }
     if (!ok) {

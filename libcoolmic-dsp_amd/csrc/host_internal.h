@@ -25,8 +25,11 @@ extern "C" {
  * rate/1000 samples, amplitude 32766; COOLMIC_ERROR_NOSYS for unsupported rates */
 int coolmic_sine_period(uint_least32_t rate, int16_t *table, size_t *samples);
 
-/* HIP device the per-object (non-batch) stages run on: $COOLMIC_HIP_DEVICE or 0 */
+/* HIP device the per-object (non-batch) stages run on: $COOLMIC_HIP_DEVICE or 0 -- unless the stage was given
+ * one of its own (coolmic_transform_set_device, coolmic_vumeter_set_device, coolmic_group_new_on) */
 int coolmic_hip_default_device(void);
+int coolmic_hip_stage_device(int chosen_plus1);
+int coolmic_hip_check_device(int device);
 
 /* Everything from here on is glue between the translation units of this library: hidden, not exported. */
 #pragma GCC visibility push(hidden)

@@ -57,6 +57,7 @@ struct coolmic_transform {
                                         * once the values they were set with have reached the device */
 
     cmhip_batch_t *dev;                /* created at the first read that needs it */
+    int device_plus1;                  /* coolmic_transform_set_device(): GPU + 1, 0 = the process's default */
     /* A VU meter downstream shares this transform's launch (one launch per pull instead of two).  All three
      * fields are published under `lock` and read once per block (transform_process):
      *   VU_DIRECT   the meter sits directly on this transform's handle: the launch accumulates the meter's
@@ -108,6 +109,24 @@ coolmic_transform_t *coolmic_transform_new(const char *name, igloo_ro_t associat
         t->chmap[c] = (uint8_t)(c < channels ? c : 0);
     t->map_identity = 1;
     return t;
+}
+
+int coolmic_transform_set_device(coolmic_transform_t *self, int device)
+{
+    int rc;
+
+    if (self == NULL)
+        return COOLMIC_ERROR_FAULT;
+    rc = coolmic_hip_check_device(device);
+    if (rc != COOLMIC_ERROR_NONE)
+        return rc;
+    pthread_mutex_lock(&self->lock);
+    if (self->dev != NULL)
+        rc = COOLMIC_ERROR_BUSY;       /* parameters, filter state and window live on the GPU it started on */
+    else
+        self->device_plus1 = device + 1;
+    pthread_mutex_unlock(&self->lock);
+    return rc;
 }
 
 int coolmic_transform_attach_iohandle(coolmic_transform_t *self, coolmic_iohandle_t *handle)
@@ -244,7 +263,9 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
     if (t->dev == NULL) {
         cmhip_batch_desc_t d;
         memset(&d, 0, sizeof(d));
-        d.device = coolmic_hip_default_device();
+        pthread_mutex_lock(&t->lock);
+        d.device = coolmic_hip_stage_device(t->device_plus1);
+        pthread_mutex_unlock(&t->lock);
         d.streams = 1;
         d.channels = t->channels;
         d.rate = (unsigned int)t->rate;

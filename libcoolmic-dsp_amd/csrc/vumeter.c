@@ -48,6 +48,7 @@ struct coolmic_vumeter {
     unsigned char buffer[VUMETER_BUFFER];
     size_t fill;
     cmhip_batch_t *dev;                /* one stream, VU only */
+    int device_plus1;                  /* coolmic_vumeter_set_device(): GPU + 1, 0 = the process's default */
     int mode;
     struct coolmic_transform *fused;   /* DIRECT / RECORDS: the upstream transform that accumulates for us
                                         * (kept alive by the handle `in`, which holds a reference) */
@@ -104,6 +105,21 @@ coolmic_vumeter_t *coolmic_vumeter_new(const char *name, igloo_ro_t associated,
     return v;
 }
 
+int coolmic_vumeter_set_device(coolmic_vumeter_t *self, int device)
+{
+    int rc;
+
+    if (self == NULL)
+        return COOLMIC_ERROR_FAULT;
+    rc = coolmic_hip_check_device(device);
+    if (rc != COOLMIC_ERROR_NONE)
+        return rc;
+    if (self->dev != NULL)
+        return COOLMIC_ERROR_BUSY;     /* the window so far is on the GPU the meter started on */
+    self->device_plus1 = device + 1;
+    return COOLMIC_ERROR_NONE;
+}
+
 /* ---- a launch of our own --------------------------------------------------------------------------- */
 
 static int meter_device(coolmic_vumeter_t *v)
@@ -113,7 +129,7 @@ static int meter_device(coolmic_vumeter_t *v)
     if (v->dev != NULL)
         return 0;
     memset(&d, 0, sizeof(d));
-    d.device = coolmic_hip_default_device();
+    d.device = coolmic_hip_stage_device(v->device_plus1);
     d.streams = 1;
     d.channels = v->channels;
     d.rate = (unsigned int)v->rate;

@@ -62,6 +62,27 @@ def test_group_server_in_c(gpu, golden, tmp_path):
                 s, exp["frames"], exp["global_peak"], exp["global_power"])
 
 
+def test_group_server_over_the_gpus_of_the_box(gpu, golden, tmp_path):
+    """examples/group_server.c with its fifth argument: one process, one coolmic_group_t per GPU made by
+    coolmic_group_new_on(), capture stream s in the group of GPU s % N, one pump thread per GPU, and at the end
+    the node-global VU over all groups -- the groups' records merged on the host and, through cmhip_node_*, by
+    RCCL, which must agree.  gpus = 0 takes every GPU the box has (one on the driver's box: N > 1 in one process
+    is unmeasured on hardware); the results do not depend on N: every stream is golden vector G1, the node
+    sees streams x G1's frames at G1's level."""
+    exp = golden["cases"]["G1"]["vu"]
+    streams = 10
+    lines = _build_and_run(tmp_path, "group_server", streams, 512, 92, 1, 0)
+    lines = [ln for ln in lines if ln.startswith(("streams ", "stream ", "node:"))]     # (librccl announces itself)
+    assert len(lines) == 4
+    n = gpu.device_count()
+    assert lines[0].startswith("streams %d block 512 pull threads 1:" % streams)
+    assert lines[0].endswith("on %d GPU(s), stream s on GPU s %% %d, one pump thread each" % (n, n))
+    for line, s in zip(lines[1:3], (0, streams - 1)):
+        assert line == "stream %d: frames %d peak %d power %.17g" % (s, exp["frames"], exp["global_peak"], exp["global_power"])
+    assert lines[3] == "node: frames %d peak %d power %.17g (%d GPU(s); host merge == RCCL exchange)" % (
+        streams * exp["frames"], exp["global_peak"], exp["global_power"], n)
+
+
 def test_node_vu_in_c(gpu, oracle, tmp_path):
     """config 5's step loop from plain C (examples/node_vu.c): streams sharded over every GPU the
     box has (one thread per GPU), node-global VU per block through cmhip_node_* (RCCL).  The

@@ -253,3 +253,96 @@ def test_group_pull_spread_over_threads(gpu, oracle, threads):
     for h in handles:
         h.unref()
     grp.unref()
+
+
+def _run_group_on(cm, oracle, device, seed):
+    """one group made through coolmic_group_new_on(device): 7 stereo streams, PCM and windows against the oracle"""
+    rng = np.random.default_rng(seed)
+    C, N, block = 2, 7, 900
+    grp = cm.Group(C, 8, block, queue_blocks=2, device=device)
+    assert grp.device == device and grp.engine()
+    xs, params, handles = [], [], []
+    for i in range(N):
+        x = oracle.lcg(seed * 100 + i, int(rng.integers(1, 4000)) * C)
+        src = cm.IoHandle.from_bytes(x.tobytes(), chunk=int(rng.choice([0, 5, 1024])))
+        assert grp.add_stream(src) == i
+        src.unref()
+        gains = [int(v) for v in rng.integers(100, 2500, C)]
+        cmap = [1, 0] if i % 2 else None
+        assert grp.set_master_gain(i, C, 1000, gains) == 0 and grp.set_channel_map(i, cmap) == 0
+        xs.append(x)
+        params.append((gains, cmap))
+        handles.append(grp.get_iohandle(i))
+    for i in range(N):
+        got = b""
+        while True:
+            n, data = handles[i].read(4096)
+            got += data
+            if n == 0 and handles[i].eof() == 1:
+                break
+        want = _expect(oracle, xs[i], C, *params[i])
+        assert np.array_equal(np.frombuffer(got, np.int16), want), (device, i)
+        rc, r = grp.vumeter_result(i)
+        v = oracle.vu_new(C)
+        oracle.vu_accumulate(v, want)
+        rc_o, r_o = oracle.vu_result(v)
+        assert rc == rc_o == 0 and r.as_dict() == of.vu_result_dict(r_o), (device, i)
+    for h in handles:
+        h.unref()
+    grp.unref()
+
+
+def test_groups_on_a_device_of_the_callers_choice(gpu, oracle):
+    """coolmic_group_new_on(): the GPU is the caller's choice, not the process-wide $COOLMIC_HIP_DEVICE -- a C host
+    with one pipeline per capture stream (ref: src/simple.c:198-200) places stream s on GPU s % N from ONE process.
+    Two groups through the call on device 0, bit-exact against the oracle (device 1: the next test)."""
+    cm = gpu
+    assert not cm.lib.coolmic_group_new_on(cm.device_count(), None, None, 48000, 2, 4, 64, 2)     # no such GPU
+    assert not cm.lib.coolmic_group_new_on(-1, None, None, 48000, 2, 4, 64, 2)
+    _run_group_on(cm, oracle, 0, 11)
+    _run_group_on(cm, oracle, 0, 12)
+
+
+def test_groups_on_a_second_device_of_the_process(gpu, oracle):
+    """the same on device 1, beside a group that stays alive on device 0 (skipped on a one-GPU box: N > 1
+    placement in one process is unmeasured on hardware until a box has two)"""
+    cm = gpu
+    if cm.device_count() < 2:
+        pytest.skip("one GPU here: needs a second one")
+    keep = cm.Group(2, 4, 256, device=0)
+    _run_group_on(cm, oracle, 1, 13)
+    _run_group_on(cm, oracle, 1, 14)
+    _run_group_on(cm, oracle, 0, 15)
+    keep.unref()
+
+
+def test_stage_device_setters(gpu, oracle):
+    """coolmic_transform_set_device / coolmic_vumeter_set_device: valid before the stage has device state of its
+    own, BUSY after, INVAL for a GPU the process does not see; the chain's results are the oracle's"""
+    cm = gpu
+    x = oracle.lcg(77, 2000)
+    tr = cm.Transform(48000, 1)
+    assert tr.set_device(cm.device_count()) == cm.ERROR_INVAL and tr.set_device(-1) == cm.ERROR_INVAL
+    assert cm.lib.coolmic_transform_set_device(None, 0) == cm.ERROR_FAULT
+    assert tr.set_device(0) == 0
+    src = cm.IoHandle.from_bytes(x.tobytes())
+    tr.attach(src); src.unref()
+    assert tr.set_master_gain(1, 1000, [1500]) == 0
+    h = tr.get_iohandle()
+    n, data = h.read(2 * 1000)
+    assert n == 2000
+    assert tr.set_device(0) == cm.ERROR_BUSY                     # the batch exists now
+    _, g = oracle.gain(1, 1, 1000, [1500])
+    assert np.array_equal(np.frombuffer(data, np.int16), oracle.gain_apply(g, x[:1000], 1))
+    vu = cm.Vumeter(48000, 1)
+    assert vu.set_device(cm.device_count()) == cm.ERROR_INVAL and vu.set_device(0) == 0
+    src2 = cm.IoHandle.from_bytes(x.tobytes())                   # a meter on a plain source: a launch of its own
+    vu.attach(src2); src2.unref()
+    assert vu.read(-1) == 1024
+    assert vu.set_device(0) == cm.ERROR_BUSY
+    rc, r = vu.result()
+    v = oracle.vu_new(1)
+    oracle.vu_accumulate(v, x[:512])
+    _, r_o = oracle.vu_result(v)
+    assert rc == 0 and r.as_dict() == of.vu_result_dict(r_o)
+    h.unref(); tr.unref(); vu.unref()

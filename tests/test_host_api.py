@@ -227,6 +227,11 @@ def test_product_fails_loudly_without_gpu(cm):
         assert vu.read(-1) == -1
         assert any(lvl == 1 and "no CPU path" in msg for lvl, msg in logs)
         assert all(msg.startswith("libcoolmic-dsp/") for _, msg in logs)
+        # device placement behind the operator API: no device is a device the process sees
+        assert tr.set_device(0) == cm.ERROR_INVAL and vu.set_device(0) == cm.ERROR_INVAL
+        assert cm.lib.coolmic_transform_set_device(None, 0) == cm.ERROR_FAULT
+        assert not cm.lib.coolmic_group_new_on(0, None, None, 48000, 2, 4, 64, 2)
+        assert any("no HIP device 0 for the group" in msg for _, msg in logs)
         h.unref(); tr.unref(); vu.unref()
     finally:
         cm.set_log_callback(None)
