@@ -87,7 +87,10 @@ int                 coolmic_group_pump(coolmic_group_t *self);
  * counts; 0 or 1: the pumping thread alone, which is how a group starts).  The handles of DIFFERENT streams
  * are then read at the same time, each stream's own handle still by one thread at a time and once per pump:
  * fine for the sources of this library and for callbacks that keep their state per stream, as the reference's
- * pipelines do with one thread each (ref: src/simple.c:292-310).  COOLMIC_ERROR_INVAL above 64. */
+ * pipelines do with one thread each (ref: src/simple.c:292-310).  Streams that were given the same handle, or
+ * handles over the same backend object (one device, one tee), are recognised when they are added and stay on
+ * the pumping thread, in slot order.  What the group cannot see -- read callbacks of different userdata that
+ * share state behind it -- is the caller's to keep thread-safe.  COOLMIC_ERROR_INVAL above 64. */
 int                 coolmic_group_set_pull_threads(coolmic_group_t *self, unsigned int threads);
 
 /* VU window of one stream since its last result; COOLMIC_ERROR_INVAL while it holds no frame */

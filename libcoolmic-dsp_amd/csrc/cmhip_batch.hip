@@ -175,6 +175,7 @@ struct cmhip_batch {
     VuState *d_ring, *h_ring;              // ring_slots x S windows on the device / pinned staging for a fetch
     unsigned int ring_slots;
     uint64_t ring_seq;                     // sequence number of the next run
+    uint64_t ring_fetched;                 // runs below this sequence number have been fetched: their slots are clear
     unsigned long long *d_dbg;             // 64 words, written only by diagnostic builds
 
     std::vector<StreamParam> h_param;
@@ -238,6 +239,14 @@ static RunTune read_tune()
     }
     if (getenv("CMHIP_PLACE_DEBUG"))
         t.place_debug = 1;
+    if (getenv("CMHIP_NO_DONE_FLAG"))
+        t.no_done_flag = 1;
+    t.done_spin_us = 200;
+    if (const char *e = getenv("CMHIP_DONE_SPIN_US")) {
+        const int v = atoi(e);
+        if (v >= 0 && v <= 20000)
+            t.done_spin_us = (uint32_t)v;
+    }
     return t;
 }
 
@@ -295,8 +304,14 @@ extern "C" void cmhip_batch_free(cmhip_batch_t *b)
     if (!b)
         return;
     (void)hipSetDevice(b->d.device);
-    if (b->collecting)
-        (void)cmhip_batch_vu_collect_end(b);
+    if (b->collecting) {
+        // a collect that was begun and never ended: the helpers may still be writing into the caller's arrays
+        // (wait for them), but nothing is finished into them HERE -- at free time those arrays may be gone
+        // (an error path of a C host, a Python binding that collected them first)
+        if (b->pool && b->d.streams >= 512)
+            b->pool->finish();
+        b->collecting = false;
+    }
     if (b->stream)
         (void)hipStreamSynchronize(b->stream);
     for (auto &e : b->ev_used) {
@@ -591,7 +606,7 @@ static int batch_init(cmhip_batch_t *b)
         HIP_TRY(hipHostMalloc((void **)&b->h_in, pcm_bytes, hipHostMallocMapped));
         memset(b->h_in, 0, pcm_bytes);
         HIP_TRY(hipHostGetDevicePointer((void **)&b->d_in, b->h_in, 0));
-        if (!getenv("CMHIP_NO_DONE_FLAG")) {             // (A/B knob)
+        if (!b->tune.no_done_flag) {                     // (A/B knob: CMHIP_NO_DONE_FLAG)
             HIP_TRY(hipHostMalloc((void **)&b->h_done, 64, hipHostMallocMapped));
             memset(b->h_done, 0, 64);
             HIP_TRY(hipHostGetDevicePointer((void **)&b->d_done, b->h_done, 0));
@@ -736,6 +751,7 @@ extern "C" cmhip_batch_t *cmhip_batch_new(const cmhip_batch_desc_t *desc)
     b->d_ring = b->h_ring = nullptr;
     b->ring_slots = 0;
     b->ring_seq = 0;
+    b->ring_fetched = 0;
     b->d_dbg = nullptr;
     b->h_pack[0] = b->h_pack[1] = b->h_pack[2] = nullptr;
     b->d_pack[0] = b->d_pack[1] = b->d_pack[2] = nullptr;
@@ -961,14 +977,16 @@ static int host_slots_quiet(cmhip_batch_t *b)
     if (b->in_flight) {
         bool done = false;
         if (b->done_flagged) {
-            // the launch's own last act was to store its sequence number here (done_epilogue): a bounded
-            // spin, then the stream after all (a kernel that faulted never stores)
-            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+            // the launch's own last act was to store its sequence number here (done_epilogue).  The spin is
+            // bounded by what such a launch can take -- one workgroup on a block of at most a few KiB: tens of
+            // microseconds, 16 384 frames through the equaliser a few hundred -- then the stream after all, which
+            // sleeps instead of holding a core (a kernel that faulted never stores; a long one is not worth a core)
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(b->tune.done_spin_us);
             unsigned spins = 0;
             while (!(done = __atomic_load_n(b->h_done, __ATOMIC_ACQUIRE) == b->done_seq)) {
-                if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() > t_end)
+                if ((++spins & 63u) == 0 && std::chrono::steady_clock::now() > t_end)
                     break;
-                __builtin_ia32_pause();
+                cmhip_cpu_relax();
             }
         }
         if (!done)
@@ -1301,6 +1319,11 @@ static int batch_run(cmhip_batch_t *b, size_t frames, const uint32_t *frames_per
     // ring mode: this run's window is a cleared slot of its own (sample indices start at 0: slot 0 of
     // VuState::samples is read, slot 1 written)
     const bool ring = vu && b->ring_slots != 0;
+    // (a slot is cleared when it is fetched: a run that wrapped onto an unfetched window would add to stale sums
+    // and keys without anybody noticing -- the owner fetches at least once per `ring_slots` runs, transform.c)
+    if (ring && b->ring_seq - b->ring_fetched >= b->ring_slots)
+        return fail(COOLMIC_ERROR_BUSY, "run: the window ring is full (%u runs unfetched): cmhip_batch_vu_ring_fetch first",
+                    b->ring_slots);
     VuState *const window = ring ? b->d_ring + (size_t)(b->ring_seq % b->ring_slots) * b->d.streams : b->d_vu;
     const uint32_t parity = ring ? 0u : b->parity;
     EventPair ev{};                          // timing: the events take the kernel's own start and end
@@ -1696,6 +1719,7 @@ extern "C" CMHIP_INTERNAL int cmhip_batch_vu_ring(cmhip_batch_t *b, unsigned int
     }
     if (b->ring_slots)
         HIP_TRY(hipMemsetAsync(b->d_ring, 0, (size_t)b->ring_slots * b->d.streams * sizeof(VuState), b->stream));
+    b->ring_fetched = b->ring_seq;           // every slot is clear
     return COOLMIC_ERROR_NONE;
 }
 
@@ -1707,9 +1731,9 @@ extern "C" CMHIP_INTERNAL int cmhip_batch_vu_ring_fetch(cmhip_batch_t *b, uint64
     if (!b || !out)
         return fail(COOLMIC_ERROR_FAULT, "vu_ring_fetch: NULL argument");
     if (!b->ring_slots || count == 0 || count > b->ring_slots || first_seq + count > b->ring_seq ||
-        b->ring_seq - first_seq > b->ring_slots)
-        return fail(COOLMIC_ERROR_INVAL, "vu_ring_fetch: runs %llu..+%u are not in the ring",
-                    (unsigned long long)first_seq, count);
+        b->ring_seq - first_seq > b->ring_slots || first_seq != b->ring_fetched)
+        return fail(COOLMIC_ERROR_INVAL, "vu_ring_fetch: runs %llu..+%u are not the oldest unfetched ones of the ring (%llu)",
+                    (unsigned long long)first_seq, count, (unsigned long long)b->ring_fetched);
     if (use(b))
         return COOLMIC_ERROR_GENERIC;
     const size_t S = b->d.streams;
@@ -1725,6 +1749,7 @@ extern "C" CMHIP_INTERNAL int cmhip_batch_vu_ring_fetch(cmhip_batch_t *b, uint64
     HIP_TRY(hipStreamSynchronize(b->stream));
     for (unsigned i = 0; i < count; i++)
         raw_from_state(b->h_ring[(size_t)((first + i) % b->ring_slots) * S], 1u, &out[i]);
+    b->ring_fetched = first_seq + count;
     return COOLMIC_ERROR_NONE;
 }
 

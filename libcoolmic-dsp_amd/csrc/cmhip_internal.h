@@ -104,6 +104,9 @@ struct RunTune {
     int32_t  place_env;            // CMHIP_PLACE: -1 unset (only batches created with CMHIP_PLACE_SEARCH search), 0 never,
                                    // 1 the first large batch of a device also without the flag, 2 every large batch
     uint32_t place_debug;          // CMHIP_PLACE_DEBUG: the probe times of the placement search on stderr
+    uint32_t no_done_flag;         // CMHIP_NO_DONE_FLAG: one-workgroup launches are waited for through the stream (A/B)
+    uint32_t done_spin_us;         // CMHIP_DONE_SPIN_US: how long the host spins on the completion word before it
+                                   // waits for the stream instead (default 200; 0 ... 20000)
 };
 
 struct EqArgs {

@@ -34,6 +34,8 @@ struct GroupStream {
     std::vector<unsigned char> spill;        // ... and what had to leave a set that was needed again
     size_t spill_pos;                        //     (older than every segment)
     size_t pending;                          // bytes in spill and segments together
+    bool shared_source;                      // another stream of the group reads the same handle or the same backend
+                                             // state: always pulled on the pumping thread, in slot order
 };
 
 struct coolmic_group {
@@ -188,6 +190,18 @@ extern "C" int coolmic_group_add_stream(coolmic_group_t *self, coolmic_iohandle_
     s.carry_fill = 0;
     s.spill_pos = 0;
     s.pending = 0;
+    s.shared_source = false;
+    // Two streams over one upstream object (the same handle twice, or two handles whose backend is one device,
+    // one file, one tee) would race on its state once the pump's reads run on several threads
+    // (coolmic_group_set_pull_threads): such streams are marked and keep being read by the pumping thread
+    // alone, one after the other, as a single-threaded pump reads everything.
+    const void *backend = coolmic_iohandle_backend(source);
+    for (auto &o : *self->streams) {
+        if (o.source == source || (backend != nullptr && coolmic_iohandle_backend(o.source) == backend)) {
+            o.shared_source = true;
+            s.shared_source = true;
+        }
+    }
     coolmic_ro_ref(source);
     self->streams->push_back(std::move(s));
     return (int)self->streams->size() - 1;
@@ -284,6 +298,7 @@ struct GroupPull {
     coolmic_group_t *g;
     int16_t *h_in;
     size_t framesize, block_bytes, queue_cap;
+    int shared;                              // -1: every stream of the range; 0 / 1: only those without / with a shared source
 };
 
 static void group_pull_range(void *arg, unsigned lo, unsigned hi)
@@ -292,6 +307,8 @@ static void group_pull_range(void *arg, unsigned lo, unsigned hi)
     coolmic_group_t *self = p->g;
     for (size_t i = lo; i < hi; i++) {
         GroupStream &s = (*self->streams)[i];
+        if (p->shared >= 0 && (int)s.shared_source != p->shared)
+            continue;
         (*self->nframes)[i] = 0;
         const size_t coming = self->in_flight ? (size_t)(*self->flight)[i] * p->framesize : 0;
         if (s.pending + coming + p->block_bytes > p->queue_cap)
@@ -346,11 +363,15 @@ extern "C" int coolmic_group_pump(coolmic_group_t *self)
     int delivered = 0;
 
     // 1. pull: one iohandle read per stream (group_pull_range), on this thread or spread over the helpers
-    const GroupPull pull = {self, h_in, framesize, block_bytes, queue_cap};
-    if (self->pullers && n >= 16)
+    GroupPull pull = {self, h_in, framesize, block_bytes, queue_cap, -1};
+    if (self->pullers && n >= 16) {
+        pull.shared = 0;                     // streams with a source of their own: spread over the helpers
         self->pullers->run(group_pull_range, (void *)&pull, (unsigned)n, 8);
-    else
+        pull.shared = 1;                     // the rest here, in slot order
         group_pull_range((void *)&pull, 0, (unsigned)n);
+    } else {
+        group_pull_range((void *)&pull, 0, (unsigned)n);
+    }
     for (size_t i = 0; i < n; i++) {
         const uint32_t fr = (*self->nframes)[i];
         if (fr > most)

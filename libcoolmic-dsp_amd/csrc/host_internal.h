@@ -35,6 +35,7 @@ int coolmic_hip_check_device(int device);
 #pragma GCC visibility push(hidden)
 
 ssize_t coolmic_transform_handle_read(void *userdata, void *buffer, size_t len);
+const void *coolmic_iohandle_backend(const coolmic_iohandle_t *self);
 ssize_t coolmic_tee_reader_read(void *userdata, void *buffer, size_t len);
 
 /* A VU meter attached directly to a transform's handle shares the transform's launch (vumeter.c,

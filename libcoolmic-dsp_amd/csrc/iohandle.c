@@ -37,6 +37,12 @@ coolmic_iohandle_t *coolmic_iohandle_new(const char *name, igloo_ro_t associated
     return h;
 }
 
+/* (internal: what a handle reads from -- two handles over the same userdata share their backend's state) */
+const void *coolmic_iohandle_backend(const coolmic_iohandle_t *self)
+{
+    return self != NULL ? self->userdata : NULL;
+}
+
 ssize_t coolmic_iohandle_read(coolmic_iohandle_t *self, void *buffer, size_t len)
 {
     unsigned char *dst = buffer;

@@ -14,6 +14,18 @@
 // Used for the dB finish of many windows (log10 + sqrt per channel and stream: with thousands of
 // streams per batch one host thread would take about as long as the GPU needs for the next block)
 // and for the per-stream queue copies of a group.
+// one step of a spin-wait, whatever the host's architecture
+static inline void cmhip_cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+    __asm__ __volatile__("yield" ::: "memory");
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
+}
+
 struct WorkPool {
     // Work is handed out in chunks of `chunk` items from a shared counter and the calling thread
     // works too, so a helper that the OS does not schedule in time (busy hosts, CPU quotas) costs
@@ -75,7 +87,7 @@ struct WorkPool {
             for (int i = 0; i < 64; i++) {
                 if (pred())
                     return true;
-                __builtin_ia32_pause();
+                cmhip_cpu_relax();
             }
             if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(us))
                 return pred();

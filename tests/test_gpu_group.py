@@ -346,3 +346,54 @@ def test_stage_device_setters(gpu, oracle):
     _, r_o = oracle.vu_result(v)
     assert rc == 0 and r.as_dict() == of.vu_result_dict(r_o)
     h.unref(); tr.unref(); vu.unref()
+
+
+def test_streams_that_share_a_source_stay_on_the_pumping_thread(gpu, oracle):
+    """coolmic_group_set_pull_threads(4): streams with a source of their own are pulled on four threads; two
+    streams that were given the SAME handle, and two with different handles over one backend (two readers of one
+    tee would be that; here two get_iohandle() of one sound device), are recognised at add_stream and read by the
+    pumping thread alone, in slot order -- so what each of them gets is what a single-threaded pump gives:
+    alternating blocks of the shared source."""
+    cm = gpu
+    C, N, block, blocks = 1, 20, 256, 6
+    grp = cm.Group(C, N, block, queue_blocks=blocks + 2)
+    assert grp.set_pull_threads(4) == 0
+    shared = oracle.lcg(4242, block * blocks * 2)
+    sh = cm.IoHandle.from_bytes(shared.tobytes())
+    dev = cm.Snddev("sine", 48000, 1)
+    xs, handles = {}, []
+    for i in range(N):
+        if i in (3, 11):
+            src = sh                                                   # one handle, twice
+        elif i in (5, 17):
+            src = dev.get_iohandle()                                   # two handles, one sine phase behind them
+        else:
+            xs[i] = oracle.lcg(7000 + i, block * blocks)
+            src = cm.IoHandle.from_bytes(xs[i].tobytes())
+        assert grp.add_stream(src) == i
+        if src is not sh:
+            src.unref()
+        assert grp.set_master_gain(i, 1, 1000, [1300]) == 0
+        handles.append(grp.get_iohandle(i))
+    sh.unref(); dev.unref()
+    for _ in range(blocks):
+        assert grp.pump() == N
+    _, g = oracle.gain(1, 1, 1000, [1300])
+    rc_s, table = oracle.sine_table(48000)
+    sine = np.tile(np.asarray(table, dtype=np.int16), block * blocks * 2 // 48 + 2)
+    for i in range(N):
+        n, data = handles[i].read(block * blocks * 2)
+        got = np.frombuffer(data, np.int16)
+        assert n == block * blocks * 2
+        if i in (3, 11):                                               # blocks 0, 2, 4 .. / 1, 3, 5 .. of the shared source
+            first = 0 if i == 3 else 1
+            want = np.concatenate([shared[(2 * k + first) * block:(2 * k + first + 1) * block] for k in range(blocks)])
+        elif i in (5, 17):
+            first = 0 if i == 5 else 1
+            want = np.concatenate([sine[(2 * k + first) * block:(2 * k + first + 1) * block] for k in range(blocks)])
+        else:
+            want = xs[i]
+        assert np.array_equal(got, oracle.gain_apply(g, want, 1)), i
+    for h in handles:
+        h.unref()
+    grp.unref()

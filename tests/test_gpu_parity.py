@@ -659,6 +659,87 @@ def test_node_exchange_through_rccl_one_rank(gpu, oracle):
     node.close()
 
 
+def test_config5_per_gpu_shape_through_the_rccl_path(gpu, oracle):
+    """BASELINE config 5 at the shape one GPU of eight carries -- 8192 mono streams x 65536 frames, gain 900/1000,
+    PCM materialised -- through the node-global VU exactly as bench.py's c5 leg drives it: per block
+    cmhip_node_partial, per NB = 4 blocks ONE cmhip_node_allreduce (ncclAllReduce(int64, sum) +
+    ncclAllReduce(uint64, max)) on a one-rank communicator (all a one-GPU box can hold; the N > 1 exchange is
+    unmeasured on hardware), then cmhip_node_fetch.  Size-independent properties, per block:
+      * the fetched record == cmhip_node_merge_host of the un-reduced record == the host form of it;
+      * its 16 + 1 sums == the sums of cmhip_batch_vu_raw over ALL 8192 streams (a checksum of checksums), its
+        frames == 8192 x 65536;
+      * its global peak key names the right sample: largest magnitude over all streams, among equals the
+        earliest frame, among those the lowest global stream id -- recomputed on the host from the generator for
+        every stream of block 0 (LCG jump-ahead in numpy), and checked against the oracle's window of that stream;
+      * sampled streams: PCM and the raw window against the oracle."""
+    cm = gpu
+    S, C, T, NB = 8192, 1, 65536, 4
+    first_global, step = 3, 8                                       # rank 3 of 8: global stream 3 + 8 s
+    node = cm.Node(0, 1, 0, cm.node_unique_id(), max_records=NB)
+    b = cm.Batch(S, C, T, flags=cm.OUT_PCM | cm.VU)
+    assert b.set_gain(-1, 1, 1000, [900]) == 0
+    _, g = oracle.gain(1, 1, 1000, [900])
+    own, sums, mags = [], [], []
+    for k in range(NB):
+        b.generate(cm.GEN_NOISE, 12345, T, first_global=first_global, global_step=step, frame_offset=k * T)
+        b.run(T)
+        own.append(b.node_record(first_global=first_global, global_step=step))
+        node.partial(b, 0, k, first_global=first_global, global_step=step)
+        tot, top = 0, 0
+        for s_ in range(S):
+            power, peak, frames = b.vu_raw(s_)
+            assert frames == T
+            tot += int(power[0])
+            top = max(top, abs(int(peak[0])))
+        sums.append(tot)
+        mags.append(top)
+        if k == 0:
+            for s_ in (0, 1, 4095, 8191):
+                want = oracle.gain_apply(g, oracle.lcg(12345 + first_global + s_ * step, T), 1)
+                assert np.array_equal(b.download(s_, T), want), s_
+                v = oracle.vu_new(1)
+                oracle.vu_accumulate(v, want)
+                power, peak, _ = b.vu_raw(s_)
+                assert int(power[0]) == int(v.power[0]) and int(peak[0]) == int(v.result.channel_peak[0]), s_
+        b.vu_reset(-1)
+    node.allreduce(0, NB, after=b)
+    got = node.fetch(0, NB)
+    for k in range(NB):
+        assert np.array_equal(got[k], own[k]), k
+        assert np.array_equal(cm.node_merge_host(own[k][None, :]), own[k]), k
+        w = got[k].astype(np.uint64)
+        assert int(w[0]) == sums[k] and int(w[16]) == S * T, k
+        assert not w[1:16].any() and not w[18:33].any()              # mono: the other channels' slots stay empty
+        assert int(w[17]) == int(w[33])                               # one channel: its key is the global one
+        assert int(w[33]) >> 46 == mags[k], k
+        rc, r = cm.node_finish(got[k], C)
+        assert rc == 0 and r.frames == S * T and abs(int(r.global_peak)) == mags[k]
+        assert r.global_power == oracle.lib.oracle_power_db(sums[k], S * T)
+    # block 0: which sample the global key names.  |x| * 900 // 1000 is largest for x = -32768 (29491; 32767 gives
+    # 29490), so the winner is the first -32768 over all streams: earliest frame, then lowest global stream.
+    a_t = np.empty(T, dtype=np.uint32)                                # x_t = a_t * seed + c_t  (t = 1 .. T draws)
+    c_t = np.empty(T, dtype=np.uint32)
+    a, c = np.uint32(1), np.uint32(0)
+    with np.errstate(over="ignore"):
+        for t in range(T):
+            a = np.uint32(a * np.uint32(1664525))
+            c = np.uint32(c * np.uint32(1664525) + np.uint32(1013904223))
+            a_t[t], c_t[t] = a, c
+        best = None
+        for s_ in range(S):
+            gs = first_global + s_ * step
+            hit = np.flatnonzero(((a_t * np.uint32(12345 + gs) + c_t) >> np.uint32(16)) == 0x8000)
+            if hit.size and (best is None or (int(hit[0]), gs) < best):
+                best = (int(hit[0]), gs)
+    assert best is not None and mags[0] == 29491
+    key = int(got[0].astype(np.uint64)[33])
+    frame = (1 << 29) - 1 - ((key >> 17) & ((1 << 29) - 1))
+    stream = 65535 - ((key >> 1) & 0xffff)
+    assert (frame, stream, key & 1) == (best[0], best[1], 1), (frame, stream, best)
+    b.close()
+    node.close()
+
+
 def test_full_size_config2_properties(gpu, oracle):
     """BASELINE config 2 at full size (4096 x 2ch x 65536 frames): sampled streams against
     the oracle, VU-only run equal to the PCM run, two half-blocks equal to one block."""
@@ -1107,3 +1188,21 @@ def test_kernel_timing_on_every_launch_and_on_a_sample(gpu):
     b.run(4096)
     assert b.timing_read()[1] == 0
     b.close()
+
+
+def test_a_batch_freed_inside_a_collect_leaves_the_callers_arrays_alone(gpu):
+    """cmhip_batch_free() between cmhip_batch_vu_collect_begin() and _end(): the helpers are waited for, nothing
+    is finished into the caller's arrays at free time (they may be gone by then) -- both forms, the helper pool
+    (512 streams and more) and the deferred one below that."""
+    cm = gpu
+    for S in (8, 1024):
+        b = cm.Batch(S, 1, 256, flags=cm.VU)
+        b.generate(cm.GEN_NOISE, 5, 256)
+        b.run(256)
+        b.vu_snapshot()
+        results = (cm.VuResult * S)()
+        rcs = (cm.C.c_int * S)(*([77] * S))
+        b.vu_collect_begin(results, rcs)
+        b.close()
+        if S < 512:                                  # the deferred form never ran: the arrays are as the caller left them
+            assert list(rcs) == [77] * S
