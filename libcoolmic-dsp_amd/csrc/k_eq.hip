@@ -130,6 +130,11 @@ __device__ __forceinline__ u32 eq_role(u32 wave)
     }
 }
 
+// CH = 0: LDS behind the tiles.  A T-in wave's eight rows touch at most 8 / C + 2 streams; a block of a stream is
+// 64 frames x C channels = 8 C vectors of 16 bytes: at most 256 vectors (C = 16: two streams) per wave.
+constexpr u32 EQ_RAWIN = 256 * 16;                // bytes of one T-in wave's raw block
+constexpr u32 EQ_STAGE_OUT = 32 * 64 * 2;         // bytes of one slot of the staged int16 result (32 rows x 64 frames)
+
 template <int NSEC, int G, int CH>
 __global__ __launch_bounds__((eq_waves<NSEC, G>() * 64))
 void k_eq_pipe(EqArgs a)
@@ -149,8 +154,23 @@ void k_eq_pipe(EqArgs a)
     constexpr int DPP_SHR1 = 0x111, DPP_SHL7 = 0x107;
     constexpr u32 HOP = 2;                        // steps from F_k to F_k+1
     constexpr u32 NSW = EQ_NSW;
-    extern __shared__ float lds[];                // NBUF buffers x 2 slots x EP_TILE floats, then G counts
-    u32 *nfr_lds = reinterpret_cast<u32 *>(lds + NBUF * 2 * EP_TILE);
+    // NBUF buffers x 2 slots x EP_TILE floats; for CH = 0 behind them the T-in waves' raw blocks (EQ_RAWIN bytes
+    // each) and two slots of EQ_STAGE_OUT bytes for the interleaved int16 result (see below).  The rows' frame
+    // counts sit in the padding of the first tile's rows (a row is 64 + 4 floats; nobody writes the four).
+    extern __shared__ float lds[];
+    auto nfr_at = [&](u32 r) -> u32 & { return reinterpret_cast<u32 *>(lds)[r * EP_ROW + EP_TB]; };
+    constexpr bool STAGE_IN = CH == 0;            // T-in: the block's interleaved PCM by 16-byte loads, through LDS
+    unsigned char *rawin = reinterpret_cast<unsigned char *>(lds + NBUF * 2 * EP_TILE);
+    unsigned char *outstage = rawin + 4u * EQ_RAWIN;
+    // The interleaved int16 result of a many-channel stream leaves through LDS as well: the S lanes hold four
+    // frames of ONE channel each, and stored as they are that is a 2-byte store every 2C bytes -- 46 % of a
+    // 5.1 launch were the S waves' stores (round 4, profiles/r04_eq_multichannel_stamps.txt).  They put their
+    // samples where they belong in a copy of the block's frames in LDS, and one step later the same waves send
+    // that copy out in whole 16-byte vectors.  Only streams whose rows ALL lie in this workgroup go that way (a
+    // vector holds samples of every channel); the one or two streams a workgroup shares with its neighbours keep
+    // the 2-byte stores -- rows are dealt out over the whole batch, 32 to a workgroup, so that 1365 x 6 channels
+    // are 256 workgroups and not 273, which would be a second round on 256 CUs.
+    const bool stage_out = CH == 0 && a.out != nullptr;
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const u32 C = MONO ? 1u : STEREO ? 2u : a.channels;
     // Rows are numbered stream * C + channel over the whole batch and a workgroup takes G
@@ -193,13 +213,13 @@ void k_eq_pipe(EqArgs a)
     const u32 sidx = live ? sl * C + my_ch : 0u;           // EqState index of this row
     const u32 my_nfr = live ? (a.nframes ? a.nframes[sl] : a.frames) : 0u;
     if (wave == 0 && lane < G)
-        nfr_lds[lane] = my_nfr;
+        nfr_at(lane) = my_nfr;
     u32 nmax = my_nfr;
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1)
         nmax = max(nmax, (u32)__shfl_xor((int)nmax, o, 64));
     const u32 nblocks = (nmax + EP_TB - 1) / EP_TB;
-    const u32 nsteps = nblocks + HOP * NSEC;
+    const u32 nsteps = nblocks + HOP * NSEC + (stage_out ? 1u : 0u);     // (the staged result leaves a step later)
     __syncthreads();
 
     // R lanes own y1, y2 of their section (EqState: x1 x2 y1 y2)
@@ -236,7 +256,7 @@ void k_eq_pipe(EqArgs a)
         l_mi = a.param[l_s].mi[l_ch];
         l_mf = a.param[l_s].mf[l_ch];
         l_m = MONO ? 0u : a.param[l_s].chmap[l_ch];       // the input channel this row reads
-        l_n = nfr_lds[l_r];
+        l_n = nfr_at(l_r);
         if (l_live) {
             // section 0 sees integer-valued samples (the 2^-15 of "x / 32768.f" is not applied
             // by the conversion): it is folded into the coefficients instead, which is
@@ -291,10 +311,39 @@ void k_eq_pipe(EqArgs a)
     // (EQ batches have rows of whole 8-frame chunks, so a chunk with a valid frame is never clamped)
     const u32 l_last = (u32)a.stride - (MONO ? 8u : STEREO ? 16u : 1u);
     const u32 l_sel = l_m ? 0x07060302u : 0x05040100u;    // STEREO: which halves of two frames make a pair
-    struct Pcm { u32x4 a, b; };                           // a chunk in flight (b: second half, STEREO only)
+    // CH = 0 (STAGE_IN): a T-in wave loads the block's interleaved PCM of the streams its eight rows belong to
+    // -- tv_n vectors of 16 bytes, lane l takes vectors l, l + 64, l + 128, l + 192 (those past tv_n repeat the
+    // last one: the loads stay unconditional) -- and when the block's turn comes passes them through its own 4 KiB
+    // of LDS, where every lane picks the eight samples of its row's channel.  (Round 3 gathered them with eight
+    // 2-byte global loads per lane: 5.1 float planes waited 350 clk of every step for them and the T-in waves
+    // beside the R waves were last at the barrier in every step, profiles/r04_eq_multichannel_stamps.txt.)
+    u32 tv_n = 0;                                         // vectors of a block of this wave's streams
+    const int16_t *tv_src[4] = {a.in, a.in, a.in, a.in};  // per lane and vector: its stream's slot ...
+    u32 tv_off[4] = {0, 0, 0, 0};                         // ... and the vector's place in a block, in samples
+    u32 l_raw = 0;                                        // byte offset of this lane's first sample in the raw block
+    if constexpr (STAGE_IN) {
+        if (is_tin) {
+            const u32 gr_first = row0_global + 8u * tw;
+            const u32 gr_end = min(min(gr_first + 8u, row0_global + rows_here), a.streams * C);    // one past the last row
+            if (gr_first < gr_end) {
+                const u32 ts_lo = gr_first / C, tnst = (gr_end - 1u) / C - ts_lo + 1u;
+                tv_n = tnst * 8u * C;                     // <= 256 (EQ_RAWIN)
+#pragma unroll
+                for (u32 u = 0; u < 4; u++) {
+                    const u32 v = min(64u * u + lane, tv_n - 1u);
+                    const u32 si = v / (8u * C), vv = v - si * 8u * C;
+                    tv_src[u] = a.in + (u64)(ts_lo + si) * a.stride;
+                    tv_off[u] = vv * 8u;
+                }
+                if (l_live)
+                    l_raw = (((l_s - ts_lo) * EP_TB + l_t8) * C + l_m) * 2u;
+            }
+        }
+    }
+    struct Pcm { u32x4 a, b, c, d; };                     // a chunk in flight (b: second half, STEREO; c, d: STAGE_IN)
     auto fetch = [&](u32 b) -> Pcm {
         const u32 f0 = b * EP_TB + l_t8;
-        Pcm r = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        Pcm r = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
         if (CMHIP_EQ_ABL & 2) {
             r.a = u32x4{f0, f0 * 3u, f0 * 5u, f0 * 7u};
         } else if constexpr (MONO) {
@@ -304,11 +353,13 @@ void k_eq_pipe(EqArgs a)
             r.a = __builtin_nontemporal_load(p);
             r.b = __builtin_nontemporal_load(p + 1);
         } else {
-            u32 h[8];                                     // frames f0..f0+7 of input channel l_m
-#pragma unroll
-            for (u32 k = 0; k < 8; k++)
-                h[k] = *reinterpret_cast<const uint16_t *>(l_src + min((f0 + k) * C + l_m, l_last));
-            r.a = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+            // (clamped into the stream's own slot, which is a whole number of vectors long: the blocks fetched
+            // ahead of a stream's end load its last vector again)
+            const u32 blk = b * EP_TB * C, last8 = (u32)a.stride - 8u;
+            r.a = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tv_src[0] + min(blk + tv_off[0], last8)));
+            r.b = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tv_src[1] + min(blk + tv_off[1], last8)));
+            r.c = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tv_src[2] + min(blk + tv_off[2], last8)));
+            r.d = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tv_src[3] + min(blk + tv_off[3], last8)));
         }
         return r;
     };
@@ -330,7 +381,7 @@ void k_eq_pipe(EqArgs a)
         keep1 = gain_one(l_n - 1u);
         keep2 = l_n >= 2u ? gain_one(l_n - 2u) : a.state[l_sidx].s[0][0];
     }
-    Pcm wa = {{0, 0, 0, 0}, {0, 0, 0, 0}}, wb = wa;       // blocks of even / odd steps
+    Pcm wa = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, wb = wa;       // blocks of even / odd steps
     if (is_tin) {
         wa = fetch(0);
         wb = fetch(1);
@@ -461,6 +512,26 @@ void k_eq_pipe(EqArgs a)
                     w[1] = __builtin_amdgcn_perm(wcur.a.w, wcur.a.z, l_sel);
                     w[2] = __builtin_amdgcn_perm(wcur.b.y, wcur.b.x, l_sel);
                     w[3] = __builtin_amdgcn_perm(wcur.b.w, wcur.b.z, l_sel);
+                }
+                if constexpr (STAGE_IN) {
+                    // the raw block into this wave's own LDS area, then this lane's eight samples out of it
+                    // (one wave: its LDS operations execute in the order issued, no barrier)
+                    unsigned char *rw = rawin + tw * EQ_RAWIN;
+                    if (lane < tv_n)
+                        *reinterpret_cast<u32x4 *>(rw + lane * 16u) = wcur.a;
+                    if (64u + lane < tv_n)
+                        *reinterpret_cast<u32x4 *>(rw + (64u + lane) * 16u) = wcur.b;
+                    if (128u + lane < tv_n)
+                        *reinterpret_cast<u32x4 *>(rw + (128u + lane) * 16u) = wcur.c;
+                    if (192u + lane < tv_n)
+                        *reinterpret_cast<u32x4 *>(rw + (192u + lane) * 16u) = wcur.d;
+                    const unsigned char *mine = rw + l_raw;
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) {
+                        const u32 lo = *reinterpret_cast<const uint16_t *>(mine + (2u * q) * 2u * C);
+                        const u32 hi = *reinterpret_cast<const uint16_t *>(mine + (2u * q + 1u) * 2u * C);
+                        w[q] = lo | (hi << 16);
+                    }
                 }
                 // (These selects are not needed for the results -- nothing beyond a stream's end is ever
                 // stored -- and the next block's load could be issued before the wait for this one's data or
@@ -611,8 +682,54 @@ void k_eq_pipe(EqArgs a)
         if (is_store && a.vu && v_stream[i] != 0xffffffffu)
             vbase[i] = a.vu[v_stream[i]].samples[a.parity];
     }
+    // stage_out: where this lane's four frames of row slot i go in a staged block ([stream of the workgroup][frame]
+    // [channel] int16, as the frames lie in global memory), and which 16-byte vector of a staged block this lane
+    // sends out a step later (the 4 x 64 S lanes cover the 256 vectors a workgroup's 32 rows x 64 frames make)
+    u32 so_base[NSL];                                     // 0xffffffff: the row's stream is shared with a neighbour
+    int16_t *co_ptr = nullptr;                            // nullptr: no vector for this lane
+    u32 co_n = 0, co_f0 = 0, co_f1 = 0, co_vec = 0, co_s8 = 0;
+#pragma unroll
+    for (u32 i = 0; i < NSL; i++)
+        so_base[i] = 0xffffffffu;
+    if (stage_out && is_store) {
+        // whole streams of this workgroup: s_fw .. s_we - 1
+        const u32 s_fw = (row0_global + C - 1u) / C;
+        const u32 s_we = min((row0_global + rows_here) / C, a.streams);
+        const u32 t4 = (lane % SPR) * 4u;
+#pragma unroll
+        for (u32 i = 0; i < NSL; i++)
+            if (v_stream[i] != 0xffffffffu && v_stream[i] >= s_fw && v_stream[i] < s_we)
+                so_base[i] = (((v_stream[i] - s_fw) * EP_TB + t4) * C + v_ch[i]) * 2u;
+        co_vec = (role & 15u) * 64u + lane;
+        const u32 si = co_vec / (8u * C), vv = co_vec - si * 8u * C;
+        if (s_fw + si < s_we) {
+            co_ptr = a.out + (u64)(s_fw + si) * a.stride + vv * 8u;
+            co_n = a.nframes ? a.nframes[s_fw + si] : a.frames;
+            co_s8 = vv * 8u;                              // the vector's first sample inside a block
+            co_f0 = co_s8 / C;                            // first and last frame (inside a block) the vector touches
+            co_f1 = (co_s8 + 7u) / C;
+        }
+    }
     auto s_step = [&](const u32 step) {
         eq_pad<CMHIP_EQ_PAD_S>();
+        if (stage_out) {
+            // the block the S waves staged in the step before leaves in whole vectors (the barrier between the two
+            // steps has made every wave's samples visible; the other slot takes this step's block meanwhile)
+            const u32 bo = step - (HOP * NSEC + 1u);
+            if (step >= HOP * NSEC + 1u && bo < nblocks && co_ptr) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(outstage + (bo & 1u) * EQ_STAGE_OUT + co_vec * 16u);
+                int16_t *dst = co_ptr + (u64)bo * EP_TB * C;
+                const u32 fb = bo * EP_TB;
+                if (fb + co_f1 < co_n) {
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst));
+                } else if (fb + co_f0 < co_n) {           // the stream ends inside this vector: sample by sample
+                    const u32 e[4] = {v.x, v.y, v.z, v.w};
+                    for (u32 j = 0; j < 8; j++)
+                        if (fb + (co_s8 + j) / C < co_n)
+                            dst[j] = (int16_t)(e[j >> 1] >> (16u * (j & 1u)));
+                }
+            }
+        }
 
         if (!(CMHIP_EQ_ABL & 1)) {
             // --- the finished block of the last section leaves: 256 B (float) / 128 B (int16)
@@ -628,7 +745,7 @@ void k_eq_pipe(EqArgs a)
 #pragma unroll
                 for (u32 i = 0; i < NSL; i++) {
                     const u32 r = min(s_row(i), (u32)G - 1u);   // (slots past s_cnt are skipped below)
-                    nin[i] = nfr_lds[r];
+                    nin[i] = nfr_at(r);
                     vin[i] = *reinterpret_cast<const float4 *>(Y + r * EP_ROW + t4);
                 }
 #pragma unroll
@@ -693,7 +810,13 @@ void k_eq_pipe(EqArgs a)
                                 } else if (ff < n) {
                                     d32[0] = d0;
                                 }
-                            } else {                      // interleaved result: this row's channel
+                            } else if (so_base[i] != 0xffffffffu) {       // interleaved result: into the staged block
+                                unsigned char *st16 = outstage + (b & 1u) * EQ_STAGE_OUT + so_base[i];
+#pragma unroll
+                                for (u32 j = 0; j < 4; j++)
+                                    *reinterpret_cast<int16_t *>(st16 + j * 2u * C) =
+                                        (int16_t)((j < 2u ? p01 : p23) >> (16u * (j & 1u)));
+                            } else {                      // ... or, a stream shared with a neighbour, this row's channel
                                 int16_t *d16 = a.out + (u64)vs_ * a.stride + (u64)f0 * C + vc_;
 #pragma unroll
                                 for (u32 j = 0; j < 4; j++)
@@ -812,7 +935,7 @@ void k_eq_pipe(EqArgs a)
             if (lane % SPR == 0 && v_stream[i] != 0xffffffffu) {
                 VuState *vs = a.vu + v_stream[i];
                 if (v_ch[i] == 0)
-                    vs->samples[a.parity ^ 1u] = vbase[i] + (u64)nfr_lds[r] * C;
+                    vs->samples[a.parity ^ 1u] = vbase[i] + (u64)nfr_at(r) * C;
                 vs->power[v_ch[i]] += pw;
                 if (ky > vs->key[v_ch[i]])
                     vs->key[v_ch[i]] = ky;
@@ -859,18 +982,19 @@ void k_eq_pipe(EqArgs a)
     done_epilogue(a.done_flag, a.done_seq);
 }
 
-template <int NSEC, int G>
+template <int NSEC, int G, int CH>
 static constexpr size_t eq_pipe_lds_bytes()
 {
-    return ((size_t)(2 * NSEC) * 2 * G * (64 + 4)) * sizeof(float) + G * sizeof(u32);
+    return ((size_t)(2 * NSEC) * 2 * G * (64 + 4)) * sizeof(float) + (CH == 0 ? 4u * EQ_RAWIN + 2u * EQ_STAGE_OUT : 0u);
 }
 
 template <int NSEC, int G, int CH>
 static hipError_t launch_eq_pipe(const EqArgs &a0, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, bool *flagged)
 {
     EqArgs a = a0;
-    constexpr size_t lds_bytes = eq_pipe_lds_bytes<NSEC, G>();
+    constexpr size_t lds_bytes = eq_pipe_lds_bytes<NSEC, G, CH>();
     static_assert(lds_bytes <= 160 * 1024, "tiles of a workgroup must fit the LDS");
+
     const u64 rows = (u64)a.streams * (CH == 1 ? 1u : a.channels);      // one row per stream and channel
     const u32 spg = CH == 1 ? G : G / a.channels;
     const u32 grid = a.whole_streams ? (a.streams + spg - 1) / spg : (u32)((rows + G - 1) / G);
@@ -901,15 +1025,22 @@ static hipError_t launch_eq_pipe_g(const EqArgs &a, hipStream_t st, hipEvent_t e
 template <int NSEC>
 static hipError_t raise_lds_limit()
 {
-    const int bytes = (int)eq_pipe_lds_bytes<NSEC, 32>();
+    // (a -DCMHIP_EQ_STAMPS build keeps 256 bytes of static LDS for its stamps: the one variant that fills the
+    // whole 160 KiB, four sections on many channels, cannot be launched in that diagnostic build)
+#ifdef CMHIP_EQ_STAMPS
+    constexpr size_t cap = 160 * 1024 - 256;
+#else
+    constexpr size_t cap = 160 * 1024;
+#endif
+    auto bytes = [](size_t want) { return (int)(want < cap ? want : cap); };
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, 32, 1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes(eq_pipe_lds_bytes<NSEC, 32, 1>()));
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, 32, 2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes(eq_pipe_lds_bytes<NSEC, 32, 2>()));
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_pipe<NSEC, 32, 0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes(eq_pipe_lds_bytes<NSEC, 32, 0>()));
     return e;
 }
 

@@ -1,9 +1,10 @@
 #!/bin/bash
 # SQ counters of the EQ pipeline kernel, one rocprofv3 --pmc pass per counter group
-# (run on the GPU box from the repo root; results under gpurun_out/eq_pmc/).
+# (run on the GPU box from the repo root; results under gpurun_out/eq_pmc_SHAPE/).  usage: eq_pmc.sh [SHAPE]
 set -e
+SHAPE=${1:-eq3}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$ROOT/gpurun_out/eq_pmc
+OUT=$ROOT/gpurun_out/eq_pmc_$SHAPE
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -13,7 +14,7 @@ for grp in "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_I
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU"; do
     i=$((i + 1))
-    rocprofv3 --pmc $grp --output-format csv -d "$OUT/p$i" -- python3 "$ROOT/tools/eq_pmc_target.py" > "$OUT/p$i.log" 2>&1
+    rocprofv3 --pmc $grp --output-format csv -d "$OUT/p$i" -- python3 "$ROOT/tools/eq_pmc_target.py" "$SHAPE" > "$OUT/p$i.log" 2>&1
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-role busy cycles of the pipelined EQ kernel (diagnostic build, `make stamps`).
-Run with COOLMIC_HIP_LIB=libcoolmic-dsp_amd/lib/libcoolmic-dsp-hip-stamps.so."""
+Run with COOLMIC_HIP_LIB=libcoolmic-dsp_amd/lib/libcoolmic-dsp-hip-stamps.so.  usage: eq_stamps.py [SHAPE]
+SHAPE: eq3 (config 3: mono float planes, default) | eq3vu1 (mono int16 + VU) | eq3vu (stereo int16 + VU) |
+eq3f6 (5.1 float planes) | eq3vu6 (5.1 int16 + VU)"""
 import ctypes as C
 import os
 import sys
@@ -9,8 +11,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 
 cm = ge.load_package()
-S, T = 8192, 65536
-b = cm.Batch(S, 1, T, flags=cm.EQ | cm.OUT_F32)
+SHAPES = {"eq3": (8192, 1, cm.OUT_F32), "eq3vu1": (8192, 1, cm.OUT_PCM | cm.VU), "eq3vu": (4096, 2, cm.OUT_PCM | cm.VU),
+          "eq3f6": (1365, 6, cm.OUT_F32), "eq3vu6": (1365, 6, cm.OUT_PCM | cm.VU)}
+shape = sys.argv[1] if len(sys.argv) > 1 else "eq3"
+S, Cn, out_flags = SHAPES[shape]
+T = 65536
+b = cm.Batch(S, Cn, T, flags=cm.EQ | out_flags)
 b.set_eq(-1, cm.eq3())
 b.set_gain(-1, 1, 1000, [900])
 b.generate(cm.GEN_NOISE, 12345, T)
@@ -21,7 +27,7 @@ out = (C.c_uint64 * 64)()
 cm.lib.cmhip_debug_read.argtypes = [C.c_void_p, C.c_void_p]
 assert cm.lib.cmhip_debug_read(b.h, out) == 0
 nsteps = out[48]
-print("G =", os.environ.get("CMHIP_EQ_G", "default"), "steps", nsteps)
+print("shape", shape, "(%d streams x %d ch)" % (S, Cn), "steps", nsteps)
 for w in range(12):
     if out[2 * w + 1] > nsteps:
         hw = out[36 + w]
