@@ -272,11 +272,10 @@ def main():
     # many chunks that takes is decided once for all ranks (collective_more): with a data-path
     # collective in the steps (config 5) every rank must issue the same number of them.
     t_w = time.perf_counter()
-    # (first MIN_WARMUP_S of load from a plain read of the batch's input array -- another kernel, k_ceiling_read --
-    # so that every launch of the benchmarked kernel, warm-up steps included, runs at the clocks the chip then
-    # holds: a rocprofv3 kernel trace of this command averages over all of them)
-    while time.perf_counter() - t_w < MIN_WARMUP_S:
-        b.ceiling(0, 8)
+    # (with the benchmarked kernel itself: 0.15 s of another kernel -- a plain read or copy of the batch's arrays --
+    # in front of a short --warmup left the timed launches 3 % slower than 0.15 s of the kernel's own launches,
+    # round 4.  A rocprofv3 trace of this command therefore holds the ramp: tools/trace_summary.py averages the
+    # timed region's launches beside the whole trace.)
     chunk = max(8, NB if node_on else 8)
     warm_steps = launch.warm_up(run_steps, args.warmup, chunk,
                                 launch.collective_more(dist, rank, world, t_w, MIN_WARMUP_S))

@@ -699,7 +699,8 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
     // The shorter forms of the gain (StreamParam::mode, chosen per stream by the host) where the VALU counts
     // most: a VU window and nothing written.  The branch is uniform: a wave works on one stream.
     constexpr bool MODES = DO_VU && !WRITE_PCM && !WRITE_F32;
-    const u32 mode = MODES ? uniform(p->mode) : GAIN_GENERAL;
+    const u32 smode = uniform(p->mode);          // the stream's gain class (StreamParam::mode)
+    const u32 mode = MODES ? smode : GAIN_GENERAL;
     u32 ch[8], df[8], mipk[4], mf[8];
     u32 so[8];                                   // MAP: byte offset of position j's source in its row
 #pragma unroll
@@ -710,9 +711,18 @@ __global__ __launch_bounds__(64) void k_run_rows(RunArgs a, u32 W, u32 rows_per_
         mf[j] = p->mf[ch[j]];
         so[j] = MAP ? 2u * ((lane_fr + df[j]) * C + p->chmap[ch[j]]) : 0u;
     }
+    // The integer parts of the gains are per-lane loads (a lane's positions have channels of their own): eight
+    // more in front of every tile -- unless the stream's class says what they are (every gain below the scale:
+    // 0; gain disabled or unity: 1), which is the common case.  (Uniform branch: a wave works on one stream.)
+    if (smode == GAIN_GENERAL) {
 #pragma unroll
-    for (u32 i = 0; i < 4; i++)
-        mipk[i] = (u32)p->mi[ch[2 * i]] | ((u32)p->mi[ch[2 * i + 1]] << 16);
+        for (u32 i = 0; i < 4; i++)
+            mipk[i] = (u32)p->mi[ch[2 * i]] | ((u32)p->mi[ch[2 * i + 1]] << 16);
+    } else {
+#pragma unroll
+        for (u32 i = 0; i < 4; i++)
+            mipk[i] = smode == GAIN_IDENTITY ? 0x00010001u : 0u;
+    }
 
     const int16_t *ins = a.in + (u64)s * a.stride;
     const u32x4 *src = reinterpret_cast<const u32x4 *>(ins);

@@ -444,7 +444,14 @@ void k_eq_pipe(EqArgs a)
 #pragma unroll
                     for (u32 t = 0; t < EP_TB / 4; t++)
                         out[t] = v[t];
-                } else if (__all(cnt == EP_TB)) {
+                } else if (__all(cnt == EP_TB || cnt == 0u)) {
+                    // (every row of the wave has the whole block or nothing of it: rows past the end of the batch,
+                    // streams that ended in an earlier block.  Those run the same instructions on whatever their tile
+                    // holds -- nothing of it is ever stored -- and get their history back afterwards.  Round 3 sent
+                    // the whole wave down the sample-by-sample path below as soon as ONE row was idle: a batch whose
+                    // rows are not a multiple of 32 -- 1365 x 6 -- had one workgroup that took 1.4 x as long as the
+                    // others for the whole launch, and the launch waited for it.)
+                    const float keep_h1 = h1, keep_h2 = h2;
                     // Where the stores go: left alone the scheduler moves all sixteen to the end of the row.  Kept
                     // behind their four samples each (a scheduling barrier per store) the runs that produce an
                     // int16 result take 2.3-3.6 % less and config 3's float planes 0.8 % more (A/B in one process,
@@ -472,6 +479,8 @@ void k_eq_pipe(EqArgs a)
                         row(std::true_type{});
                     else
                         row(std::false_type{});
+                    h1 = cnt ? h1 : keep_h1;
+                    h2 = cnt ? h2 : keep_h2;
                 } else {
                     // some stream ends inside this block: same arithmetic, but the history of a
                     // lane moves only on its real samples (what lies beyond is never stored)
@@ -809,6 +818,29 @@ void k_eq_pipe(EqArgs a)
                                     __builtin_nontemporal_store(pk, reinterpret_cast<u32x2 *>(d32));
                                 } else if (ff < n) {
                                     d32[0] = d0;
+                                }
+                            } else if ((C & 1u) == 0u) {
+                                // An even channel count: the rows of a slot's lanes L and L + 32 are channels 2k and
+                                // 2k + 1 of one stream (s_row; rows are dealt out from even numbers), so the two swap
+                                // halves as the stereo form does -- L keeps frames f0, f0 + 1 of both channels, L + 32
+                                // frames f0 + 2, f0 + 3 -- and every sample pair is one aligned dword of a frame:
+                                // two 4-byte stores per lane instead of four 2-byte ones, staged or not.
+                                typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+                                const u32x2 sw2 = __builtin_amdgcn_permlane32_swap(p01, p23, false, false);
+                                const u32 d0 = __builtin_amdgcn_perm(sw2.y, sw2.x, 0x05040100u);
+                                const u32 d1 = __builtin_amdgcn_perm(sw2.y, sw2.x, 0x07060302u);
+                                const u32 hi = lane >> 5;                 // this lane's row is the odd channel of the pair
+                                if (so_base[i] != 0xffffffffu) {
+                                    unsigned char *st32 = outstage + (b & 1u) * EQ_STAGE_OUT + so_base[i] - 2u * hi + hi * 4u * C;
+                                    *reinterpret_cast<u32 *>(st32) = d0;
+                                    *reinterpret_cast<u32 *>(st32 + 2u * C) = d1;
+                                } else {
+                                    const u32 ff = f0 + 2u * hi;
+                                    int16_t *d16 = a.out + (u64)vs_ * a.stride + (u64)ff * C + (vc_ - hi);
+                                    if (ff < n)
+                                        *reinterpret_cast<u32 *>(d16) = d0;
+                                    if (ff + 1u < n)
+                                        *reinterpret_cast<u32 *>(d16 + C) = d1;
                                 }
                             } else if (so_base[i] != 0xffffffffu) {       // interleaved result: into the staged block
                                 unsigned char *st16 = outstage + (b & 1u) * EQ_STAGE_OUT + so_base[i];

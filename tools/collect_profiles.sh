@@ -8,6 +8,7 @@ for w in c2 c2ro c2ro_below c2ro_off c3 x6; do
     cp gpurun_out/${w}_rocprof.json profiles/${R}_${w}_bench_under_rocprof.json
     # (gpurun merges into gpurun_out/, so older runs' files may still be there: take the newest)
     cp "$(ls -t gpurun_out/prof_$w/*/*_kernel_stats.csv | head -1)" profiles/${R}_${w}_kernel_stats.csv
+    cp gpurun_out/${w}_trace_summary.json profiles/${R}_${w}_trace_summary.json
 done
 for w in c2 c2ro c3 x6 c2ro_below c2ro_off; do
     cp gpurun_out/pmc_$w.json profiles/${R}_${w}_pmc.json

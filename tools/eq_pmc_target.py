@@ -10,7 +10,8 @@ import __graft_entry__ as ge
 
 cm = ge.load_package()
 SHAPES = {"eq3": (8192, 1, cm.OUT_F32), "eq3vu1": (8192, 1, cm.OUT_PCM | cm.VU), "eq3vu": (4096, 2, cm.OUT_PCM | cm.VU),
-          "eq3f6": (1365, 6, cm.OUT_F32), "eq3vu6": (1365, 6, cm.OUT_PCM | cm.VU)}
+          "eq3f6": (1365, 6, cm.OUT_F32), "eq3vu6": (1365, 6, cm.OUT_PCM | cm.VU),
+          "eq3f4": (2048, 4, cm.OUT_F32), "eq3f3": (2730, 3, cm.OUT_F32), "eq3f16": (512, 16, cm.OUT_F32)}
 S, Cn, out_flags = SHAPES[sys.argv[1] if len(sys.argv) > 1 else "eq3"]
 T = 65536
 b = cm.Batch(S, Cn, T, flags=cm.EQ | out_flags)

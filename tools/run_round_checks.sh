@@ -17,8 +17,9 @@ prof() {    # name, bench arguments...
     local name=$1; shift
     rm -rf $R/gpurun_out/prof_$name
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$name -- \
-        python3 $R/bench.py "$@" --steps 100 --warmup 100 --no-cpu --no-extras > $R/gpurun_out/${name}_rocprof.json 2> $R/gpurun_out/${name}_rocprof.err
+        python3 $R/bench.py "$@" --steps 200 --warmup 20 --no-cpu --no-extras > $R/gpurun_out/${name}_rocprof.json 2> $R/gpurun_out/${name}_rocprof.err
     cat $R/gpurun_out/${name}_rocprof.json
+    python3 $R/tools/trace_summary.py $R/gpurun_out/prof_$name $R/gpurun_out/${name}_rocprof.json $R/gpurun_out/${name}_trace_summary.json
 }
 # (--no-extras: every launch of the kernel in a trace is a step of the bench; the batch's arrays lie where hipMalloc
 # first puts them -- the library's default, and what the default line's `value` and `roofline` are measured on)
