@@ -215,6 +215,33 @@ def test_igloo_glue_uses_the_references_igloo_surface():
     assert os.path.exists(os.path.join(REFERENCE, "src", "types_private.h"))
 
 
+def test_no_scalar_load_with_a_register_and_an_immediate_offset():
+    """On gfx950 with ROCm 7.2 an `s_load_dword sdst, sbase, soffset offset:imm` came back from sbase + imm alone:
+    the register offset did not reach the address (round 4, profiles/NOTES_r04.md -- a uniform, run-time indexed
+    load of a stream's parameters in the stereo read-only kernel; golden vector G4 caught it on the GPU).  The
+    kernels avoid the form (fixed offsets + scalar selects); this holds the generated assembly of all three kernel
+    files to that, on the CPU, before anything reaches a GPU.  It also keeps scratch memory out of the hot kernels:
+    a spilled register means a private segment per wave."""
+    import subprocess
+    pkg = os.path.join(ROOT, "libcoolmic-dsp_amd")
+    subprocess.run(["make", "-s", "-C", pkg, "asm"], check=True)
+    bad = []
+    for name in ("k_block", "k_eq", "k_misc"):
+        text = open(os.path.join(pkg, "build", name + ".s")).read()
+        assert "s_load_dword" in text and ".amdhsa_kernel" in text, name
+        for ln in text.splitlines():
+            if re.search(r"^\s*s_(buffer_)?load_dword\w*\s+\S+,\s*s\[\d+:\d+\],\s*s\d+\s+offset:", ln):
+                bad.append((name, ln.strip()))
+    assert not bad, bad[:5]
+    usage = open(os.path.join(pkg, "build", "k_block.usage.txt")).read()
+    spills = {}
+    for m in re.finditer(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", usage, flags=re.S):
+        spills[m.group(1)] = int(m.group(2))
+    hot = [n for n in spills if "k_run_fast" in n and ("Li16E" in n or "ELb1ELb0ELb1ELi4ELi4E" in n)]
+    assert hot, "the mono / stereo kernels of configs 2, 4, 5 and of the read-only leg were not found"
+    assert not [n for n in hot if spills[n]], [n for n in hot if spills[n]]
+
+
 def test_host_feature_tokens_of_the_dropin_build():
     """inside the reference's build coolmic_features() lists the HOST's encoders and drivers (handed in by its
     Makefile) plus the token of this path (ref: src/coolmic-dsp.c:64-83)"""
