@@ -721,7 +721,7 @@ void k_eq_pipe(EqArgs a)
     }
     auto s_step = [&](const u32 step) {
         eq_pad<CMHIP_EQ_PAD_S>();
-        if (stage_out) {
+        if (stage_out && !(CMHIP_EQ_ABL & 2048)) {                       // (2048: timing only, nothing copied out)
             // the block the S waves staged in the step before leaves in whole vectors (the barrier between the two
             // steps has made every wave's samples visible; the other slot takes this step's block meanwhile)
             const u32 bo = step - (HOP * NSEC + 1u);
@@ -830,7 +830,8 @@ void k_eq_pipe(EqArgs a)
                                 const u32 d0 = __builtin_amdgcn_perm(sw2.y, sw2.x, 0x05040100u);
                                 const u32 d1 = __builtin_amdgcn_perm(sw2.y, sw2.x, 0x07060302u);
                                 const u32 hi = lane >> 5;                 // this lane's row is the odd channel of the pair
-                                if (so_base[i] != 0xffffffffu) {
+                                if (CMHIP_EQ_ABL & 1024) {                 // (1024: timing only, the result goes nowhere)
+                                } else if (so_base[i] != 0xffffffffu) {
                                     unsigned char *st32 = outstage + (b & 1u) * EQ_STAGE_OUT + so_base[i] - 2u * hi + hi * 4u * C;
                                     *reinterpret_cast<u32 *>(st32) = d0;
                                     *reinterpret_cast<u32 *>(st32 + 2u * C) = d1;
@@ -856,7 +857,7 @@ void k_eq_pipe(EqArgs a)
                                         d16[j * C] = (int16_t)((j < 2u ? p01 : p23) >> (16u * (j & 1u)));
                             }
                         }
-                        if (a.vu) {
+                        if (a.vu && !(CMHIP_EQ_ABL & 512)) {            // (512: timing only, no window)
                             // The window of the int16 result on packed pairs (as the block kernels do): the
                             // magnitudes of four samples in six instructions, their squares in one chain of
                             // three v_mad_u32_u16 and a fourth, and one comparison of the four's maximum
