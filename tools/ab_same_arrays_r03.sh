@@ -1,3 +1,8 @@
+# The round's build against round 3's on the SAME array pairs (tools/placement_forms.py with another build named).
+# The other build is not in the tree; make it first, in the container:
+#   git worktree add /tmp/r03 ee2608b && make -C /tmp/r03/libcoolmic-dsp_amd -j8 &&
+#   cp /tmp/r03/libcoolmic-dsp_amd/lib/libcoolmic-dsp-hip.so libcoolmic-dsp_amd/lib/libcoolmic-dsp-hip-r03.so
+# (built libraries travel to the GPU box; the copy is git-ignored).  -> gpurun_out/r04_same_arrays_r03_vs_r04.txt
 set -e
 L=libcoolmic-dsp_amd/lib
 O=gpurun_out/r04_same_arrays_r03_vs_r04.txt
