@@ -273,17 +273,20 @@ static int transform_process(coolmic_transform_t *t, int16_t *pcm, size_t frames
         /* (always with a VU window: whether a meter reads it is decided later, and a batch made
          * anew would lose the equaliser's state) */
         d.flags = CMHIP_OUT_PCM | CMHIP_INPLACE | CMHIP_EQ | CMHIP_HOSTPCM | CMHIP_VU;
-        t->dev = cmhip_batch_new(&d);
-        if (t->dev == NULL) {
-            coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_NOSYS,
-                                "no HIP engine for the transform (there is no CPU path): %s",
-                                cmhip_last_error());
-            return -1;
+        {
+            cmhip_batch_t *dev = cmhip_batch_new(&d);
+            if (dev == NULL) {
+                coolmic_logging_log(COOLMIC_LOGGING_LEVEL_ERROR, COOLMIC_ERROR_NOSYS,
+                                    "no HIP engine for the transform (there is no CPU path): %s",
+                                    cmhip_last_error());
+                return -1;
+            }
+            dirty = 1;
+            pthread_mutex_lock(&t->lock);
+            t->dev = dev;              /* (under the lock: coolmic_transform_set_device looks at it from any thread) */
+            t->vu_reset_pending = 0;   /* a new batch's window is empty */
+            pthread_mutex_unlock(&t->lock);
         }
-        dirty = 1;
-        pthread_mutex_lock(&t->lock);
-        t->vu_reset_pending = 0;       /* a new batch's window is empty */
-        pthread_mutex_unlock(&t->lock);
         vu_reset = 0;
     }
     if (vu_reset && cmhip_batch_vu_reset(t->dev, 0) != COOLMIC_ERROR_NONE)
